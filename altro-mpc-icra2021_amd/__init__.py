@@ -2,6 +2,12 @@
 
 The compute path is the HIP shared library built from csrc/ and reached through the C-ABI
 declared in include/altro_batch.h.  This package mirrors the Altro.jl /
-TrajectoryOptimization.jl call surface the reference's benchmark scripts use.
+TrajectoryOptimization.jl call surface the reference's benchmark scripts use (api.py) and
+restates the reference's problem generators and MPC harness (problems.py, mpc.py).
 """
-from . import problems  # noqa: F401
+from . import _lib, mpc, problems  # noqa: F401
+from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, LinearModel, Problem,  # noqa: F401
+                  SolverOptions, TrackingObjective, controls, cost, get_duals, initial_controls,
+                  iterations, max_violation, set_duals, set_initial_state, set_options, shift_fill,
+                  solve, states, stats, status, timing_get, timing_reset, update_trajectory,
+                  work_counters)

@@ -1,0 +1,127 @@
+"""ctypes binding of libaltro_hip.so (C-ABI: include/altro_batch.h).
+
+There is no fallback: if the HIP library has not been built, or no HIP device is usable, the
+calls raise.  Nothing in this package computes a solve on the CPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libaltro_hip.so")
+
+TRACE_LEN = 16
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = range(5)
+CON_BOX, CON_LINEAR, CON_SOC = 0, 1, 2
+SENSE_EQ, SENSE_INEQ = 0, 1
+
+STATUS_NAMES = ["UNSOLVED", "SOLVE_SUCCEEDED", "MAX_ITERATIONS", "MAX_ITERATIONS_OUTER",
+                "MAXIMUM_COST", "STATE_LIMIT", "CONTROL_LIMIT", "NO_PROGRESS", "COST_INCREASE"]
+SOLVE_SUCCEEDED = 1
+
+EXPORTS = [
+    "altro_default_opts", "altro_batch_create", "altro_batch_destroy", "altro_last_error",
+    "altro_batch_set_dynamics", "altro_batch_set_tracking_cost", "altro_batch_add_constraint",
+    "altro_batch_update_constraint_data", "altro_batch_set_initial_state",
+    "altro_batch_set_reference", "altro_batch_set_initial_trajectory", "altro_batch_shift_fill",
+    "altro_batch_set_options", "altro_batch_solve", "altro_batch_solve_async",
+    "altro_batch_synchronize", "altro_batch_get_states", "altro_batch_get_controls",
+    "altro_batch_get_duals", "altro_batch_set_duals", "altro_batch_get_stats",
+    "altro_batch_last_solve_ms", "altro_batch_timing_reset", "altro_batch_timing_get",
+    "altro_batch_get_work_counters", "altro_mpc_set_track", "altro_mpc_set_noise",
+    "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
+]
+"""every symbol include/altro_batch.h declares"""
+
+
+class Dims(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("N", C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "cost_tolerance", "cost_tolerance_intermediate", "gradient_tolerance",
+        "gradient_tolerance_intermediate", "constraint_tolerance", "penalty_initial",
+        "penalty_scaling", "penalty_max", "dual_max", "line_search_lower_bound",
+        "line_search_upper_bound", "max_cost_value", "max_state_value", "max_control_value",
+        "bp_reg_initial", "bp_reg_increase_factor", "bp_reg_max", "bp_reg_min", "bp_reg_fp")] + \
+        [(k, C.c_int32) for k in (
+            "iterations", "iterations_inner", "iterations_outer", "iterations_linesearch",
+            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order")]
+
+
+class AltroError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libaltro_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False, verbose=False):
+    """Generate the DPP block include and compile the HIP library for gfx950, in tree."""
+    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "gen_dpp_blocks.py")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "altro_batch.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    subprocess.check_call(["python3", os.path.join(CSRC, "gen_dpp_blocks.py"), os.path.join(CSRC, "dpp_blocks.inc")])
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(CSRC, "altro_batch.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libaltro_hip.so.  Raises if it is missing: there is no CPU path to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AltroError(-1, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    H = C.c_void_p
+    L.altro_default_opts.argtypes = [C.POINTER(Opts)]
+    L.altro_batch_create.argtypes = [C.POINTER(Dims), C.POINTER(Opts), C.c_int32, C.POINTER(H)]
+    L.altro_batch_destroy.argtypes = [H]
+    L.altro_last_error.argtypes = [H]
+    L.altro_last_error.restype = C.c_char_p
+    L.altro_batch_set_dynamics.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32]
+    L.altro_batch_set_tracking_cost.argtypes = [H, dp, dp, dp, C.c_double]
+    L.altro_batch_add_constraint.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             dp, dp, dp, dp, C.c_int32, ip]
+    L.altro_batch_update_constraint_data.argtypes = [H, C.c_int32, dp, dp]
+    L.altro_batch_set_initial_state.argtypes = [H, dp]
+    L.altro_batch_get_initial_state.argtypes = [H, dp]
+    L.altro_batch_set_reference.argtypes = [H, dp, dp]
+    L.altro_batch_set_initial_trajectory.argtypes = [H, dp, dp]
+    L.altro_batch_shift_fill.argtypes = [H, C.c_int32, C.c_int32]
+    L.altro_batch_set_options.argtypes = [H, C.POINTER(Opts)]
+    L.altro_batch_solve.argtypes = [H]
+    L.altro_batch_solve_async.argtypes = [H]
+    L.altro_batch_synchronize.argtypes = [H]
+    L.altro_batch_get_states.argtypes = [H, dp]
+    L.altro_batch_get_controls.argtypes = [H, dp]
+    L.altro_batch_get_duals.argtypes = [H, C.c_int32, dp]
+    L.altro_batch_set_duals.argtypes = [H, C.c_int32, dp]
+    L.altro_batch_get_stats.argtypes = [H, ip, ip, ip, dp, dp, dp, dp]
+    L.altro_batch_last_solve_ms.argtypes = [H, C.POINTER(C.c_float)]
+    L.altro_batch_timing_reset.argtypes = [H]
+    L.altro_batch_timing_get.argtypes = [H, C.POINTER(C.c_float), C.c_int32, ip]
+    L.altro_batch_get_work_counters.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.altro_mpc_set_track.argtypes = [H, dp, dp, C.c_int32]
+    L.altro_mpc_set_noise.argtypes = [H, dp, C.c_int32]
+    L.altro_mpc_step_async.argtypes = [H, C.c_int32]
+    L.altro_batch_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    for name in EXPORTS:
+        if name != "altro_last_error":
+            getattr(L, name).restype = C.c_int32
+    _lib = L
+    return L

@@ -1,0 +1,310 @@
+"""Host-side mirror of the Altro.jl / TrajectoryOptimization.jl / RobotDynamics.jl calls the
+reference's benchmark scripts make, for a BATCH of independent instances solved on MI355X.
+
+Julia name (reference call site)                      -> here
+  RD.LinearModel(A, B[, d]; dt)   (random_linear_problem.jl:8)  -> LinearModel
+  TO.TrackingObjective / LQRObjective (mpc.jl:29)      -> TrackingObjective
+  BoundConstraint(n,m,u_min,u_max) (random_linear_problem.jl:23) -> BoundConstraint
+  ConstraintList / add_constraint! (random_linear_problem.jl:22-24) -> ConstraintList.add_constraint
+  Problem(model,obj,xf,tf;x0,constraints) (mpc.jl:42)  -> Problem
+  SolverOptions(...) / set_options! (run_random_linear.jl:41-49) -> SolverOptions / set_options
+  ALTROSolver(prob, opts) (random_linear_problem.jl:87) -> ALTROSolver
+  solve!(altro) (:113)                                  -> solve(altro)
+  TO.set_initial_state! (:130)                          -> set_initial_state(altro, x0)
+  TO.update_trajectory!(obj, Z_track, k) (:133)         -> update_trajectory(altro, Xref, Uref)
+  RD.shift_fill!(Z) (:136), Altro.shift_fill!(conSet) (:139) -> shift_fill(altro, primal, dual)
+  states / controls / iterations / status / cost / max_violation (:166-181) -> same names
+  benchmark_solve!(altro; samples, evals) (:161)        -> benchmark_solve(altro, ...)
+
+Arrays are numpy, instance-major: X (B, N, n), U (B, N-1, m), A (B, n, n) in natural
+(row, col) indexing; conversion to the C-ABI's column-major blocks happens here.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import AltroError, SOLVE_SUCCEEDED, STATUS_NAMES  # noqa: F401
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+def SolverOptions(**kw):
+    """Altro.SolverOptions with Altro.jl's defaults; keyword names as in the reference."""
+    o = _lib.Opts()
+    rc = _lib.lib().altro_default_opts(C.byref(o))
+    if rc:
+        raise AltroError(rc, "altro_default_opts")
+    for k, v in kw.items():
+        if k in ("projected_newton", "verbose", "show_summary", "static_bp", "save_S",
+                 "projected_newton_tolerance"):
+            # accepted for source compatibility: projected_newton is false in every MPC run of
+            # the reference (run_random_linear.jl:48) and is not built; the others only affect
+            # printing or Julia-side memory layout.
+            if k == "projected_newton" and v:
+                raise AltroError(_lib.ERR_UNSUPPORTED, "projected_newton=true is not built")
+            continue
+        if not hasattr(o, k):
+            raise KeyError(f"unknown SolverOptions field {k}")
+        setattr(o, k, v)
+    return o
+
+
+@dataclass
+class LinearModel:
+    """x+ = A x + B u (+ d).  A: (n,n) shared or (B,n,n) per instance."""
+    A: np.ndarray
+    B: np.ndarray
+    d: Optional[np.ndarray] = None
+    dt: float = 0.1
+
+
+@dataclass
+class TrackingObjective:
+    """Diagonal tracking cost about (Xref, Uref); stage costs are scaled by dt."""
+    Q: np.ndarray
+    R: np.ndarray
+    Qf: np.ndarray
+    Xref: np.ndarray   # (B, N, n)
+    Uref: np.ndarray   # (B, N-1, m)
+
+
+@dataclass
+class BoundConstraint:
+    n: int
+    m: int
+    x_min: Optional[np.ndarray] = None
+    x_max: Optional[np.ndarray] = None
+    u_min: Optional[np.ndarray] = None
+    u_max: Optional[np.ndarray] = None
+
+    def zbounds(self):
+        def full(v, k, fill):
+            if v is None:
+                return np.full(k, fill)
+            return np.broadcast_to(np.asarray(v, dtype=np.float64), (k,)).copy()
+        zmin = np.r_[full(self.x_min, self.n, -np.inf), full(self.u_min, self.m, -np.inf)]
+        zmax = np.r_[full(self.x_max, self.n, np.inf), full(self.u_max, self.m, np.inf)]
+        return zmin, zmax
+
+
+@dataclass
+class ConstraintList:
+    n: int
+    m: int
+    N: int
+    items: List = field(default_factory=list)
+
+    def add_constraint(self, con, inds):
+        """inds: 1-based inclusive range (first, last) as in Julia's `1:N-1`."""
+        first, last = (inds.start, inds.stop - 1) if isinstance(inds, range) else inds
+        self.items.append((con, int(first), int(last)))
+
+
+@dataclass
+class Problem:
+    model: LinearModel
+    obj: TrackingObjective
+    constraints: ConstraintList
+    x0: np.ndarray          # (B, n)
+    N: int
+    U0: Optional[np.ndarray] = None  # (B, N-1, m) initial controls; default: the reference controls
+
+    @property
+    def batch(self):
+        return self.x0.shape[0]
+
+
+class ALTROSolver:
+    """ALTROSolver(prob, opts): owns a device-resident batch of solver workspaces."""
+
+    def __init__(self, prob: Problem, opts=None, device=0):
+        L = _lib.lib()
+        self._L = L
+        self.prob = prob
+        B, n = prob.x0.shape
+        m = np.asarray(prob.obj.R).shape[-1]
+        self.B, self.n, self.m, self.N = B, n, m, prob.N
+        self.opts = opts if opts is not None else SolverOptions()
+        dims = _lib.Dims(B, n, m, prob.N)
+        h = C.c_void_p()
+        rc = L.altro_batch_create(C.byref(dims), C.byref(self.opts), device, C.byref(h))
+        if rc:
+            raise AltroError(rc, L.altro_last_error(None).decode())
+        self.h = h
+        self.con_ids = []
+        mdl = prob.model
+        A = np.asarray(mdl.A, dtype=np.float64)
+        Bm = np.asarray(mdl.B, dtype=np.float64)
+        per_instance = A.ndim == 3
+        Ac = _c(np.swapaxes(A, -1, -2))
+        Bc = _c(np.swapaxes(Bm, -1, -2))
+        dc = _c(mdl.d) if mdl.d is not None else None
+        self._chk(L.altro_batch_set_dynamics(h, _p(Ac), _p(Bc), _p(dc), 0, int(per_instance)))
+        self._chk(L.altro_batch_set_tracking_cost(h, _p(_c(prob.obj.Q)), _p(_c(prob.obj.R)), _p(_c(prob.obj.Qf)), mdl.dt))
+        for con, first, last in prob.constraints.items:
+            if isinstance(con, BoundConstraint):
+                zmin, zmax = con.zbounds()
+                cid = C.c_int32(-1)
+                self._chk(L.altro_batch_add_constraint(h, _lib.CON_BOX, _lib.SENSE_INEQ, first - 1, last - 1, 0,
+                                                       None, None, _p(_c(zmin)), _p(_c(zmax)), 0, C.byref(cid)))
+                self.con_ids.append(cid.value)
+            else:
+                raise AltroError(_lib.ERR_UNSUPPORTED, f"constraint type {type(con).__name__} is not built yet")
+        update_trajectory(self, prob.obj.Xref, prob.obj.Uref)
+        set_initial_state(self, prob.x0)
+        U0 = prob.U0 if prob.U0 is not None else prob.obj.Uref
+        initial_controls(self, U0)
+
+    def _chk(self, rc):
+        if rc:
+            raise AltroError(rc, self._L.altro_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.altro_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def set_options(solver, **kw):
+    for k, v in kw.items():
+        setattr(solver.opts, k, v)
+    solver._chk(solver._L.altro_batch_set_options(solver.h, C.byref(solver.opts)))
+
+
+def set_initial_state(solver, x0):
+    x0 = _c(x0)
+    assert x0.shape == (solver.B, solver.n)
+    solver._chk(solver._L.altro_batch_set_initial_state(solver.h, _p(x0)))
+
+
+def update_trajectory(solver, Xref, Uref):
+    Xr, Ur = _c(Xref), _c(Uref)
+    assert Xr.shape == (solver.B, solver.N, solver.n) and Ur.shape == (solver.B, solver.N - 1, solver.m)
+    solver._chk(solver._L.altro_batch_set_reference(solver.h, _p(Xr), _p(Ur)))
+
+
+def initial_controls(solver, U):
+    U = _c(U)
+    assert U.shape == (solver.B, solver.N - 1, solver.m)
+    solver._chk(solver._L.altro_batch_set_initial_trajectory(solver.h, None, _p(U)))
+
+
+def shift_fill(solver, primal=True, dual=True):
+    solver._chk(solver._L.altro_batch_shift_fill(solver.h, int(primal), int(dual)))
+
+
+def solve(solver):
+    solver._chk(solver._L.altro_batch_solve(solver.h))
+    return solver
+
+
+def states(solver):
+    X = np.empty((solver.B, solver.N, solver.n))
+    solver._chk(solver._L.altro_batch_get_states(solver.h, _p(X)))
+    return X
+
+
+def controls(solver):
+    U = np.empty((solver.B, solver.N - 1, solver.m))
+    solver._chk(solver._L.altro_batch_get_controls(solver.h, _p(U)))
+    return U
+
+
+def get_duals(solver, con=0):
+    first, last = solver.prob.constraints.items[con][1:]
+    nk = last - first + 1
+    lam = np.empty((solver.B, nk, 2, solver.n + solver.m))
+    solver._chk(solver._L.altro_batch_get_duals(solver.h, solver.con_ids[con], _p(lam)))
+    return lam
+
+
+def set_duals(solver, lam, con=0):
+    lam = _c(lam)
+    solver._chk(solver._L.altro_batch_set_duals(solver.h, solver.con_ids[con], _p(lam)))
+
+
+@dataclass
+class Stats:
+    iterations: np.ndarray
+    iterations_outer: np.ndarray
+    status: np.ndarray
+    cost: np.ndarray
+    c_max: np.ndarray
+    cost_trace: np.ndarray
+    cmax_trace: np.ndarray
+    tsolve_ms: float
+
+
+def stats(solver):
+    B = solver.B
+    it = np.empty(B, dtype=np.int32)
+    ito = np.empty(B, dtype=np.int32)
+    st = np.empty(B, dtype=np.int32)
+    cost_ = np.empty(B)
+    cm = np.empty(B)
+    jt = np.empty((B, _lib.TRACE_LEN))
+    ct = np.empty((B, _lib.TRACE_LEN))
+    solver._chk(solver._L.altro_batch_get_stats(
+        solver.h, it.ctypes.data_as(_IP), ito.ctypes.data_as(_IP), st.ctypes.data_as(_IP),
+        _p(cost_), _p(cm), _p(jt), _p(ct)))
+    ms = C.c_float(0)
+    rc = solver._L.altro_batch_last_solve_ms(solver.h, C.byref(ms))
+    return Stats(it, ito, st, cost_, cm, jt, ct, ms.value if rc == 0 else float("nan"))
+
+
+def iterations(solver):
+    return stats(solver).iterations
+
+
+def status(solver):
+    return stats(solver).status
+
+
+def cost(solver):
+    return stats(solver).cost
+
+
+def max_violation(solver):
+    return stats(solver).c_max
+
+
+def timing_reset(solver):
+    solver._chk(solver._L.altro_batch_timing_reset(solver.h))
+
+
+def timing_get(solver):
+    """Durations (ms) of every solve-kernel launch since timing_reset, from HIP events recorded
+    on the library's own stream."""
+    cnt = C.c_int32(0)
+    solver._chk(solver._L.altro_batch_timing_get(solver.h, None, 0, C.byref(cnt)))
+    ms = np.zeros(cnt.value, dtype=np.float32)
+    if cnt.value:
+        solver._chk(solver._L.altro_batch_timing_get(solver.h, ms.ctypes.data_as(C.POINTER(C.c_float)), cnt.value, C.byref(cnt)))
+    return ms
+
+
+def work_counters(solver):
+    """(backward passes, rollouts) per instance since timing_reset."""
+    nb = np.zeros(solver.B, dtype=np.int64)
+    nr = np.zeros(solver.B, dtype=np.int64)
+    solver._chk(solver._L.altro_batch_get_work_counters(
+        solver.h, nb.ctypes.data_as(C.POINTER(C.c_int64)), nr.ctypes.data_as(C.POINTER(C.c_int64))))
+    return nb, nr

@@ -1,0 +1,814 @@
+// altro_batch.hip -- C-ABI (include/altro_batch.h) of the MI355X batched ALTRO solver.
+//
+// Host logic only: owns device memory (lane layout, DESIGN.md "Data layout in HBM"), converts
+// the caller's instance-major host arrays to/from it with small pack kernels, and launches the
+// solve kernel of solve_dpp16.h.  There is no CPU compute path in this library: every entry
+// point that computes launches HIP kernels, and creation fails if no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/altro_batch.h"
+#include "solve_dpp16.h"
+
+using altro::IPW;
+using altro::LW;
+
+static thread_local std::string g_create_err;
+
+struct altro_handle {
+  altro_dims d{};
+  altro_opts o{};
+  int device = 0;
+  int Bp = 0;  // batch padded to a multiple of IPW
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::vector<hipEvent_t> hist;  // start/end event pairs of solve launches since the last reset
+  size_t hist_used = 0;
+  long long *n_backward = nullptr, *n_rollout = nullptr;
+  // problem data (device)
+  double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
+  double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
+  double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lhi = nullptr, *Llo = nullptr, *mu = nullptr,
+         *KD = nullptr;
+  double *noise = nullptr;
+  int* cur = nullptr;
+  int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
+  double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr;
+  double* stage = nullptr;  // device staging buffer for host<->device layout conversion
+  size_t stage_bytes = 0;
+  int Nt = 0;    // knots held by Zref
+  int kref = 0;  // current reference window start
+  int noise_steps = 0;
+  int box_k0 = 0, box_k1 = -1, box_id = -1;
+  int ncon = 0;
+  bool have_dyn = false, have_cost = false, have_ref = false;
+  bool dyn_per_instance = false;
+  double dt = 0.0;
+  std::string err;
+};
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return ALTRO_ERR_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+#define FAIL(h, code, msg) \
+  do {                     \
+    (h)->err = (msg);      \
+    return (code);         \
+  } while (0)
+
+static int ensure_stage(altro_handle* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return ALTRO_OK;
+  if (h->stage) HIPCHK(h, hipFree(h->stage));
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  HIPCHK(h, hipMalloc(&h->stage, bytes));
+  h->stage_bytes = bytes;
+  return ALTRO_OK;
+}
+
+// ------------------------------------------------------------------ layout kernels
+// All take one thread per (instance slot, lane); padded slots mirror instance B-1.
+
+__global__ void k_pack_traj(const double* __restrict__ X, const double* __restrict__ U, double* __restrict__ Zp,
+                            const int* __restrict__ cur, size_t plane, int B, int Bp, int N, int n, int m,
+                            int use_cur, int have_x) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = inst < B ? inst : B - 1;
+  double* dst = Zp + (use_cur ? (size_t)cur[inst] * plane : 0);
+  for (int k = 0; k < N; ++k) {
+    double v = 0.0;
+    bool wr = false;
+    if (j < n) {
+      if (have_x) { v = X[((size_t)b * N + k) * n + j]; wr = true; }
+    } else if (j < n + m) {
+      if (k < N - 1) v = U[((size_t)b * (N - 1) + k) * m + (j - n)];
+      wr = true;
+    } else {
+      wr = true;
+    }
+    if (wr) dst[((size_t)k * Bp + inst) * LW + j] = v;
+  }
+}
+
+__global__ void k_unpack_traj(double* __restrict__ X, double* __restrict__ U, const double* __restrict__ Zp,
+                              const int* __restrict__ cur, size_t plane, int B, int Bp, int N, int n, int m) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const double* src = Zp + (size_t)cur[inst] * plane;
+  for (int k = 0; k < N; ++k) {
+    const double v = src[((size_t)k * Bp + inst) * LW + j];
+    if (j < n) {
+      if (X) X[((size_t)inst * N + k) * n + j] = v;
+    } else if (j < n + m && k < N - 1) {
+      if (U) U[((size_t)inst * (N - 1) + k) * m + (j - n)] = v;
+    }
+  }
+}
+
+// reference: Xref [B][Nt][n], Uref [B][Nt-1][m] -> Zref [Nt][Bp][16]
+__global__ void k_pack_ref(const double* __restrict__ X, const double* __restrict__ U, double* __restrict__ Zr,
+                           int B, int Bp, int Nt, int n, int m) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = inst < B ? inst : B - 1;
+  for (int k = 0; k < Nt; ++k) {
+    double v = 0.0;
+    if (j < n) v = X[((size_t)b * Nt + k) * n + j];
+    else if (j < n + m && k < Nt - 1) v = U[((size_t)b * (Nt - 1) + k) * m + (j - n)];
+    Zr[((size_t)k * Bp + inst) * LW + j] = v;
+  }
+}
+
+// dynamics: A [nb][n*n] col-major, Bm [nb][n*m] col-major, f [nb][n]; nb = B or 1
+__global__ void k_pack_dyn(const double* __restrict__ A, const double* __restrict__ Bm, const double* __restrict__ f,
+                           double* __restrict__ Gcol, double* __restrict__ Grow, double* __restrict__ fvec,
+                           int B, int Bp, int n, int m, int per_instance) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = per_instance ? (inst < B ? inst : B - 1) : 0;
+  const double* Ab = A + (size_t)b * n * n;
+  const double* Bb = Bm + (size_t)b * n * m;
+  // Gcol[inst][k][j] = G[k][j], G = [A B]
+  for (int k = 0; k < n; ++k) {
+    double v = 0.0;
+    if (j < n) v = Ab[k + n * j];
+    else if (j < n + m) v = Bb[k + n * (j - n)];
+    Gcol[((size_t)inst * n + k) * LW + j] = v;
+  }
+  // Grow[inst][c][i=j] = G[j][c]
+  for (int c = 0; c < LW; ++c) {
+    double v = 0.0;
+    if (j < n) {
+      if (c < n) v = Ab[j + n * c];
+      else if (c < n + m) v = Bb[j + n * (c - n)];
+    }
+    Grow[((size_t)inst * LW + c) * LW + j] = v;
+  }
+  fvec[(size_t)inst * LW + j] = (f && j < n) ? f[(size_t)b * n + j] : 0.0;
+}
+
+__global__ void k_pack_x0(const double* __restrict__ x0, double* __restrict__ dst, int B, int Bp, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = inst < B ? inst : B - 1;
+  dst[t] = j < n ? x0[(size_t)b * n + j] : 0.0;
+}
+
+__global__ void k_unpack_x0(double* __restrict__ x0, const double* __restrict__ src, int B, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * LW) return;
+  const int inst = t / LW, j = t % LW;
+  if (j < n) x0[(size_t)inst * n + j] = src[t];
+}
+
+// box duals: host [B][nk][2][nz]  <->  Lhi/Llo [N][Bp][16]
+__global__ void k_duals(double* __restrict__ host, double* __restrict__ Lhi, double* __restrict__ Llo, int B, int Bp,
+                        int nz, int k0, int k1, int to_host) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = inst < B ? inst : B - 1;
+  const int nk = k1 - k0 + 1;
+  for (int k = k0; k <= k1; ++k) {
+    const size_t di = ((size_t)k * Bp + inst) * LW + j;
+    if (j < nz) {
+      const size_t hi = (((size_t)b * nk + (k - k0)) * 2 + 0) * nz + j;
+      const size_t lo = (((size_t)b * nk + (k - k0)) * 2 + 1) * nz + j;
+      if (to_host) {
+        if (inst < B) { host[hi] = Lhi[di]; host[lo] = Llo[di]; }
+      } else {
+        Lhi[di] = host[hi];
+        Llo[di] = host[lo];
+      }
+    } else if (!to_host) {
+      Lhi[di] = 0.0;
+      Llo[di] = 0.0;
+    }
+  }
+}
+
+// RD.shift_fill!(Z) on the current plane and Altro.shift_fill!(conSet) on the box duals
+// (random_linear_problem.jl:136,139): entry k <- entry k+1, last entry kept.
+__global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, size_t plane, double* __restrict__ Lhi,
+                        double* __restrict__ Llo, int Bp, int N, int n, int m, int k0, int k1, int primal, int dual) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const size_t ks = (size_t)Bp * LW;
+  const size_t off = (size_t)inst * LW + j;
+  if (primal) {
+    double* z = Zp + (size_t)cur[inst] * plane + off;
+    const int kend = (j < n) ? N - 1 : N - 2;  // x: knots 0..N-2 take k+1; u: knots 0..N-3
+    if (j < n + m)
+      for (int k = 0; k < kend; ++k) z[(size_t)k * ks] = z[(size_t)(k + 1) * ks];
+  }
+  if (dual && k1 >= k0) {
+    for (int k = k0; k < k1; ++k) {
+      Lhi[(size_t)k * ks + off] = Lhi[(size_t)(k + 1) * ks + off];
+      Llo[(size_t)k * ks + off] = Llo[(size_t)(k + 1) * ks + off];
+    }
+  }
+}
+
+// Plant step of the MPC loop (random_linear_problem.jl:128-130):
+//   x0 <- A x_1 + B u_1 + f + randn(n) * ||x0||_inf / 100
+// one 16-lane group per instance; noise are unit normals supplied by the caller.
+__global__ void k_plant_step(const double* __restrict__ Zp, const int* __restrict__ cur, size_t plane,
+                             const double* __restrict__ Grow, const double* __restrict__ fvec,
+                             const double* __restrict__ noise, double* __restrict__ x0, int B, int Bp, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  const int b = inst < B ? inst : B - 1;
+  const double* z0 = Zp + (size_t)cur[inst] * plane + (size_t)inst * LW;  // knot 0
+  double acc = fvec[(size_t)inst * LW + j];
+  for (int c = 0; c < LW; ++c) acc += Grow[((size_t)inst * LW + c) * LW + j] * z0[c];
+  double a = j < n ? fabs(acc) : 0.0;
+  for (int s = 8; s >= 1; s >>= 1) a = fmax(a, __shfl_xor(a, s, LW));
+  const double nz = (noise && j < n) ? noise[(size_t)b * n + j] : 0.0;
+  x0[(size_t)inst * LW + j] = j < n ? acc + nz * a / 100.0 : 0.0;
+}
+
+__global__ void k_fill(double* p, double v, size_t nelem) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nelem) p[t] = v;
+}
+
+// ------------------------------------------------------------------ helpers
+static inline dim3 grid_for(size_t threads, int block = 256) { return dim3((unsigned)((threads + block - 1) / block)); }
+
+static bool supported_dims(int n, int m) {
+  return (n == 12 && m == 4) || (n == 6 && m == 3) || (n == 6 && m == 6) || (n == 8 && m == 4);
+}
+
+static int launch_solve(altro_handle* h) {
+  altro::SolveParams p{};
+  p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
+  p.kref = h->kref;
+  p.box_k0 = h->box_k0; p.box_k1 = h->box_k1;
+  p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
+  p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
+  p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
+  p.Lhi = h->Lhi; p.Llo = h->Llo; p.mu = h->mu; p.KD = h->KD;
+  p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
+  p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace;
+  p.n_backward = h->n_backward; p.n_rollout = h->n_rollout;
+  p.o = h->o;
+  const dim3 grid(h->Bp / IPW), block(64);
+  const int n = h->d.n, m = h->d.m;
+  if (n == 12 && m == 4) hipLaunchKernelGGL((altro::solve_kernel<12, 4>), grid, block, 0, h->stream, p);
+  else if (n == 6 && m == 3) hipLaunchKernelGGL((altro::solve_kernel<6, 3>), grid, block, 0, h->stream, p);
+  else if (n == 6 && m == 6) hipLaunchKernelGGL((altro::solve_kernel<6, 6>), grid, block, 0, h->stream, p);
+  else if (n == 8 && m == 4) hipLaunchKernelGGL((altro::solve_kernel<8, 4>), grid, block, 0, h->stream, p);
+  else FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
+  HIPCHK(h, hipGetLastError());
+  return ALTRO_OK;
+}
+
+static int check_ready(altro_handle* h) {
+  if (!h->have_dyn) FAIL(h, ALTRO_ERR_STATE, "altro_batch_set_dynamics has not been called");
+  if (!h->have_cost) FAIL(h, ALTRO_ERR_STATE, "altro_batch_set_tracking_cost has not been called");
+  if (!h->have_ref) FAIL(h, ALTRO_ERR_STATE, "no reference trajectory (altro_batch_set_reference / altro_mpc_set_track)");
+  return ALTRO_OK;
+}
+
+static int upload(altro_handle* h, const double* host, size_t count, size_t stage_off_elems = 0) {
+  HIPCHK(h, hipMemcpyAsync(h->stage + stage_off_elems, host, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return ALTRO_OK;
+}
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+int32_t altro_default_opts(altro_opts* o) {
+  if (!o) return ALTRO_ERR_INVALID_ARG;
+  o->cost_tolerance = 1e-4;
+  o->cost_tolerance_intermediate = 1e-4;
+  o->gradient_tolerance = 10.0;
+  o->gradient_tolerance_intermediate = 1.0;
+  o->constraint_tolerance = 1e-6;
+  o->penalty_initial = NAN;
+  o->penalty_scaling = NAN;
+  o->penalty_max = 1e8;
+  o->dual_max = 1e8;
+  o->line_search_lower_bound = 1e-8;
+  o->line_search_upper_bound = 10.0;
+  o->max_cost_value = 1e8;
+  o->max_state_value = 1e8;
+  o->max_control_value = 1e8;
+  o->bp_reg_initial = 0.0;
+  o->bp_reg_increase_factor = 1.6;
+  o->bp_reg_max = 1e8;
+  o->bp_reg_min = 1e-8;
+  o->bp_reg_fp = 10.0;
+  o->iterations = 1000;
+  o->iterations_inner = 300;
+  o->iterations_outer = 30;
+  o->iterations_linesearch = 20;
+  o->dJ_counter_limit = 10;
+  o->reset_duals = 1;
+  o->reset_penalties = 1;
+  o->bp_reg = 0;
+  o->soc_second_order = 1;
+  return ALTRO_OK;
+}
+
+const char* altro_last_error(const altro_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32_t device, altro_handle** out) {
+  if (!dims || !out) { g_create_err = "null argument"; return ALTRO_ERR_INVALID_ARG; }
+  *out = nullptr;
+  if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
+  if (!supported_dims(dims->n, dims->m)) {
+    g_create_err = "unsupported (n, m): kernels are built for (12,4), (6,3), (6,6), (8,4)";
+    return ALTRO_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) {
+    g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+    return ALTRO_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return ALTRO_ERR_INVALID_ARG; }
+  altro_handle* h = new (std::nothrow) altro_handle();
+  if (!h) { g_create_err = "out of host memory"; return ALTRO_ERR_INVALID_ARG; }
+  h->d = *dims;
+  if (opts) h->o = *opts; else altro_default_opts(&h->o);
+  h->device = device;
+  h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
+  auto fail = [&](const char* what, hipError_t er) {
+    g_create_err = std::string(what) + ": " + hipGetErrorString(er);
+    altro_batch_destroy(h);
+    return ALTRO_ERR_HIP;
+  };
+#define CCHK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) return fail(#call, e2); } while (0)
+  CCHK(hipSetDevice(device));
+  CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CCHK(hipEventCreate(&h->ev0));
+  CCHK(hipEventCreate(&h->ev1));
+  const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
+  const size_t row = Bp * LW;
+  CCHK(hipMalloc(&h->Gcol, Bp * n * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->Grow, Bp * LW * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->fvec, row * sizeof(double)));
+  CCHK(hipMalloc(&h->wd, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->wf, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->zmin, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->zmax, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->x0, row * sizeof(double)));
+  CCHK(hipMalloc(&h->Z, 2 * N * row * sizeof(double)));
+  CCHK(hipMalloc(&h->Lhi, N * row * sizeof(double)));
+  CCHK(hipMalloc(&h->Llo, N * row * sizeof(double)));
+  CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
+  CCHK(hipMalloc(&h->KD, (N - 1) * Bp * m * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
+  CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
+  CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
+  CCHK(hipMalloc(&h->status, Bp * sizeof(int)));
+  CCHK(hipMalloc(&h->cost, Bp * sizeof(double)));
+  CCHK(hipMalloc(&h->cmax, Bp * sizeof(double)));
+  CCHK(hipMalloc(&h->Jtrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+  CCHK(hipMalloc(&h->ctrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+  CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
+  CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
+  CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->Z, 0, 2 * N * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Lhi, 0, N * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Llo, 0, N * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->KD, 0, (N - 1) * Bp * m * LW * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
+  CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));
+  CCHK(hipMemsetAsync(h->iters_outer, 0, Bp * sizeof(int), h->stream));
+  CCHK(hipMemsetAsync(h->status, 0, Bp * sizeof(int), h->stream));
+  CCHK(hipMemsetAsync(h->cost, 0, Bp * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->cmax, 0, Bp * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Jtrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->ctrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->x0, 0, row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->fvec, 0, row * sizeof(double), h->stream));
+  {
+    // no bounds until a BOX constraint is added
+    std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
+    CCHK(hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipStreamSynchronize(h->stream));
+  }
+  hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->mu, 1.0, (size_t)Bp);
+  CCHK(hipStreamSynchronize(h->stream));
+#undef CCHK
+  *out = h;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_destroy(altro_handle* h) {
+  if (!h) return ALTRO_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lhi, h->Llo,
+                  h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
+                  h->ctrace, h->stage, h->n_backward, h->n_rollout};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (hipEvent_t e : h->hist) hipEventDestroy(e);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
+                                 int32_t per_knot, int32_t per_instance) {
+  if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
+  if (per_knot) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot (LTV) dynamics are not built yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = h->d.n, m = h->d.m;
+  const size_t nb = per_instance ? h->d.batch : 1;
+  const size_t tot = nb * (n * n + n * m + n);
+  int rc = ensure_stage(h, tot * sizeof(double));
+  if (rc) return rc;
+  if ((rc = upload(h, A, nb * n * n, 0))) return rc;
+  if ((rc = upload(h, B, nb * n * m, nb * n * n))) return rc;
+  if (f && (rc = upload(h, f, nb * n, nb * (n * n + n * m)))) return rc;
+  hipLaunchKernelGGL(k_pack_dyn, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage,
+                     h->stage + nb * n * n, f ? h->stage + nb * (n * n + n * m) : nullptr, h->Gcol, h->Grow, h->fvec,
+                     h->d.batch, h->Bp, (int)n, (int)m, per_instance ? 1 : 0);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_dyn = true;
+  h->dyn_per_instance = per_instance != 0;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const double* Rd, const double* Qfd, double dt) {
+  if (!h || !Qd || !Rd || !Qfd || !(dt > 0)) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int n = h->d.n, m = h->d.m;
+  std::vector<double> wd(LW, 0.0), wf(LW, 0.0);
+  for (int j = 0; j < n; ++j) { wd[j] = dt * Qd[j]; wf[j] = Qfd[j]; }
+  for (int j = 0; j < m; ++j) wd[n + j] = dt * Rd[j];
+  HIPCHK(h, hipMemcpyAsync(h->wd, wd.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->wf, wf.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->dt = dt;
+  h->have_cost = true;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first, int32_t k_last,
+                                   int32_t p, const double* A, const double* b, const double* zmin, const double* zmax,
+                                   int32_t per_knot, int32_t* con_id) {
+  (void)sense; (void)p; (void)A; (void)b; (void)per_knot;
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  if (k_first < 0 || k_last >= h->d.N || k_last < k_first) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad knot range");
+  if (kind != ALTRO_CON_BOX) FAIL(h, ALTRO_ERR_UNSUPPORTED, "only BOX constraints are built in this round (LINEAR / SOC: next)");
+  if (h->box_id >= 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "one BOX constraint per problem");
+  if (!zmin || !zmax) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nz = h->d.n + h->d.m;
+  std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
+  for (int j = 0; j < nz; ++j) { lo[j] = zmin[j]; hi[j] = zmax[j]; }
+  HIPCHK(h, hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->box_k0 = k_first;
+  h->box_k1 = k_last;
+  h->box_id = h->ncon++;
+  if (con_id) *con_id = h->box_id;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A, const double* b) {
+  (void)con_id; (void)A; (void)b;
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data (LINEAR / SOC) is not built in this round");
+}
+
+int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
+  if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t cnt = (size_t)h->d.batch * h->d.n;
+  int rc = ensure_stage(h, cnt * sizeof(double));
+  if (rc) return rc;
+  if ((rc = upload(h, x0, cnt))) return rc;
+  hipLaunchKernelGGL(k_pack_x0, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->x0, h->d.batch,
+                     h->Bp, h->d.n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_initial_state(altro_handle* h, double* x0) {
+  if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t cnt = (size_t)h->d.batch * h->d.n;
+  int rc = ensure_stage(h, cnt * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unpack_x0, grid_for((size_t)h->d.batch * LW), dim3(256), 0, h->stream, h->stage, h->x0,
+                     h->d.batch, h->d.n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(x0, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+static int set_ref_common(altro_handle* h, const double* Xref, const double* Uref, int Nt) {
+  const size_t B = h->d.batch, n = h->d.n, m = h->d.m;
+  const size_t cx = B * Nt * n, cu = B * (Nt - 1) * m;
+  int rc = ensure_stage(h, (cx + cu) * sizeof(double));
+  if (rc) return rc;
+  if (h->Nt != Nt) {
+    if (h->Zref) HIPCHK(h, hipFree(h->Zref));
+    h->Zref = nullptr;
+    HIPCHK(h, hipMalloc(&h->Zref, (size_t)Nt * h->Bp * LW * sizeof(double)));
+    h->Nt = Nt;
+  }
+  if ((rc = upload(h, Xref, cx, 0))) return rc;
+  if ((rc = upload(h, Uref, cu, cx))) return rc;
+  hipLaunchKernelGGL(k_pack_ref, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->stage + cx,
+                     h->Zref, h->d.batch, h->Bp, Nt, (int)n, (int)m);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->kref = 0;
+  h->have_ref = true;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_set_reference(altro_handle* h, const double* Xref, const double* Uref) {
+  if (!h || !Xref || !Uref) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  return set_ref_common(h, Xref, Uref, h->d.N);
+}
+
+int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, const double* U) {
+  if (!h || !U) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->d.batch, N = h->d.N, n = h->d.n, m = h->d.m;
+  const size_t cx = X ? B * N * n : 0, cu = B * (N - 1) * m;
+  int rc = ensure_stage(h, (cx + cu) * sizeof(double));
+  if (rc) return rc;
+  if (X && (rc = upload(h, X, cx, 0))) return rc;
+  if ((rc = upload(h, U, cu, cx))) return rc;
+  const size_t plane = N * (size_t)h->Bp * LW;
+  hipLaunchKernelGGL(k_pack_traj, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->stage + cx, h->Z,
+                     h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m, 1, X ? 1 : 0);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t plane = (size_t)h->d.N * h->Bp * LW;
+  hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lhi,
+                     h->Llo, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0);
+  HIPCHK(h, hipGetLastError());
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
+  if (!h || !o) return ALTRO_ERR_INVALID_ARG;
+  h->o = *o;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_solve_async(altro_handle* h) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (h->kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  if (h->o.reset_duals && h->box_k1 >= h->box_k0) {
+    const size_t bytes = (size_t)h->d.N * h->Bp * LW * sizeof(double);
+    HIPCHK(h, hipMemsetAsync(h->Lhi, 0, bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->Llo, 0, bytes, h->stream));
+  }
+  if (h->hist_used + 2 > h->hist.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      HIPCHK(h, hipEventCreate(&e));
+      h->hist.push_back(e);
+    }
+  }
+  HIPCHK(h, hipEventRecord(h->hist[h->hist_used], h->stream));
+  rc = launch_solve(h);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->hist[h->hist_used + 1], h->stream));
+  h->hist_used += 2;
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_synchronize(altro_handle* h) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_solve(altro_handle* h) {
+  int rc = altro_batch_solve_async(h);
+  if (rc) return rc;
+  return altro_batch_synchronize(h);
+}
+
+static int get_traj(altro_handle* h, double* X, double* U) {
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->d.batch, N = h->d.N, n = h->d.n, m = h->d.m;
+  const size_t cx = B * N * n, cu = B * (N - 1) * m;
+  int rc = ensure_stage(h, (cx + cu) * sizeof(double));
+  if (rc) return rc;
+  const size_t plane = N * (size_t)h->Bp * LW;
+  hipLaunchKernelGGL(k_unpack_traj, grid_for(B * LW), dim3(256), 0, h->stream, X ? h->stage : nullptr,
+                     U ? h->stage + cx : nullptr, h->Z, h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m);
+  HIPCHK(h, hipGetLastError());
+  if (X) HIPCHK(h, hipMemcpyAsync(X, h->stage, cx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (U) HIPCHK(h, hipMemcpyAsync(U, h->stage + cx, cu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_states(altro_handle* h, double* X) {
+  if (!h || !X) return ALTRO_ERR_INVALID_ARG;
+  return get_traj(h, X, nullptr);
+}
+
+int32_t altro_batch_get_controls(altro_handle* h, double* U) {
+  if (!h || !U) return ALTRO_ERR_INVALID_ARG;
+  return get_traj(h, nullptr, U);
+}
+
+static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_host) {
+  if (con_id != h->box_id || h->box_id < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown constraint id");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nz = h->d.n + h->d.m;
+  const size_t nk = h->box_k1 - h->box_k0 + 1;
+  const size_t cnt = (size_t)h->d.batch * nk * 2 * nz;
+  int rc = ensure_stage(h, cnt * sizeof(double));
+  if (rc) return rc;
+  if (!to_host && (rc = upload(h, lambda, cnt))) return rc;
+  hipLaunchKernelGGL(k_duals, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->Lhi, h->Llo,
+                     h->d.batch, h->Bp, nz, h->box_k0, h->box_k1, to_host);
+  HIPCHK(h, hipGetLastError());
+  if (to_host) HIPCHK(h, hipMemcpyAsync(lambda, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_duals(altro_handle* h, int32_t con_id, double* lambda) {
+  if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
+  return duals_xfer(h, con_id, lambda, 1);
+}
+
+int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lambda) {
+  if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
+  return duals_xfer(h, con_id, const_cast<double*>(lambda), 0);
+}
+
+int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* iterations_outer, int32_t* status,
+                              double* cost, double* c_max, double* cost_trace, double* cmax_trace) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->d.batch;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (iterations) HIPCHK(h, hipMemcpy(iterations, h->iters, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (iterations_outer) HIPCHK(h, hipMemcpy(iterations_outer, h->iters_outer, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (status) HIPCHK(h, hipMemcpy(status, h->status, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(h, hipMemcpy(cost, h->cost, B * sizeof(double), hipMemcpyDeviceToHost));
+  if (c_max) HIPCHK(h, hipMemcpy(c_max, h->cmax, B * sizeof(double), hipMemcpyDeviceToHost));
+  if (cost_trace) HIPCHK(h, hipMemcpy(cost_trace, h->Jtrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+  if (cmax_trace) HIPCHK(h, hipMemcpy(cmax_trace, h->ctrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms) {
+  if (!h || !ms) return ALTRO_ERR_INVALID_ARG;
+  if (!h->timed) FAIL(h, ALTRO_ERR_STATE, "no solve has been launched");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_timing_reset(altro_handle* h) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->hist_used = 0;
+  HIPCHK(h, hipMemsetAsync(h->n_backward, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->n_rollout, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count) {
+  if (!h || !count) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int32_t n = (int32_t)(h->hist_used / 2);
+  *count = n;
+  for (int32_t i = 0; ms && i < n && i < capacity; ++i)
+    HIPCHK(h, hipEventElapsedTime(&ms[i], h->hist[2 * i], h->hist[2 * i + 1]));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t B = h->d.batch;
+  if (backward_passes) HIPCHK(h, hipMemcpy(backward_passes, h->n_backward, B * sizeof(long long), hipMemcpyDeviceToHost));
+  if (rollouts) HIPCHK(h, hipMemcpy(rollouts, h->n_rollout, B * sizeof(long long), hipMemcpyDeviceToHost));
+  return ALTRO_OK;
+}
+
+int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double* Utrack, int32_t Nt) {
+  if (!h || !Xtrack || !Utrack) return ALTRO_ERR_INVALID_ARG;
+  if (Nt < h->d.N) FAIL(h, ALTRO_ERR_INVALID_ARG, "track shorter than the horizon");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = set_ref_common(h, Xtrack, Utrack, Nt);
+  if (rc) return rc;
+  // initial_trajectory!(prob, Z): the first window of the track (mpc.jl:19-20,45)
+  const size_t row = (size_t)h->Bp * LW;
+  HIPCHK(h, hipMemsetAsync(h->cur, 0, h->Bp * sizeof(int), h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->Z, h->Zref, (size_t)h->d.N * row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->x0, h->Zref, row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  // x0 lanes >= n must be zero: u lanes of Zref knot 0 hold u_0, clear them through the pack path
+  {
+    const size_t cnt = (size_t)h->d.batch * h->d.n;
+    std::vector<double> x0(cnt);
+    const size_t n = h->d.n;
+    for (size_t b = 0; b < (size_t)h->d.batch; ++b)
+      for (size_t j = 0; j < n; ++j) x0[b * n + j] = Xtrack[(b * Nt + 0) * n + j];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    rc = altro_batch_set_initial_state(h, x0.data());
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ALTRO_OK;
+}
+
+int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps) {
+  if (!h || !noise || steps < 1) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->noise) HIPCHK(h, hipFree(h->noise));
+  h->noise = nullptr;
+  const size_t cnt = (size_t)steps * h->d.batch * h->d.n;
+  HIPCHK(h, hipMalloc(&h->noise, cnt * sizeof(double)));
+  HIPCHK(h, hipMemcpy(h->noise, noise, cnt * sizeof(double), hipMemcpyHostToDevice));
+  h->noise_steps = steps;
+  return ALTRO_OK;
+}
+
+int32_t altro_mpc_step_async(altro_handle* h, int32_t step) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (step < 0 || (h->noise && step >= h->noise_steps)) FAIL(h, ALTRO_ERR_INVALID_ARG, "step outside the uploaded noise");
+  if (step + 1 + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "step runs past the end of the track");
+  const size_t plane = (size_t)h->d.N * h->Bp * LW;
+  const double* nz = h->noise ? h->noise + (size_t)step * h->d.batch * h->d.n : nullptr;
+  // x0 <- plant(x_1, u_1) + noise          (random_linear_problem.jl:128-130)
+  hipLaunchKernelGGL(k_plant_step, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Grow,
+                     h->fvec, nz, h->x0, h->d.batch, h->Bp, h->d.n);
+  HIPCHK(h, hipGetLastError());
+  // update_trajectory!(obj, Z_track, k_mpc)  (random_linear_problem.jl:133)
+  h->kref = step + 1;
+  // shift_fill! primal then dual             (random_linear_problem.jl:136,139)
+  rc = altro_batch_shift_fill(h, 1, 1);
+  if (rc) return rc;
+  // solve!                                   (random_linear_problem.jl:161)
+  return altro_batch_solve_async(h);
+}
+
+int32_t altro_batch_get_stream(altro_handle* h, void** stream) {
+  if (!h || !stream) return ALTRO_ERR_INVALID_ARG;
+  *stream = (void*)h->stream;
+  return ALTRO_OK;
+}
+
+}  // extern "C"

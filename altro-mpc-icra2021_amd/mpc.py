@@ -1,0 +1,70 @@
+"""MPC harness for batches: restates benchmarks/mpc.jl::gen_tracking_problem (:11-47) and the
+loop of benchmarks/random_linear_mpc/random_linear_problem.jl::run_MPC (:85-189) on top of the
+batched solver.  The OSQP twin of the reference is replaced by the offline oracle in tests/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, api
+
+REF_OPTS = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-4,
+                penalty_initial=1000.0, penalty_scaling=100.0, reset_duals=0)
+"""SolverOptions of run_random_linear.jl:41-49 (projected_newton=false is the only built mode)."""
+
+
+def gen_tracking_problem(pb, N=None):
+    """gen_tracking_problem(prob, N): tracking cost Q=10 I, R=0.1 I, Qf=10 I about the first N
+    knots of the long trajectory, same bound constraint on knots 1..N-1 (mpc.jl:11-47)."""
+    N = pb.N if N is None else N
+    n, m = pb.n, pb.m
+    Xr, Ur = pb.Xtrack[:, :N], pb.Utrack[:, :N - 1]
+    model = api.LinearModel(pb.A, pb.Bm, dt=pb.dt)
+    obj = api.TrackingObjective(np.full(n, pb.Qk), np.full(m, pb.Rk), np.full(n, pb.Qfk), Xr, Ur)
+    cons = api.ConstraintList(n, m, N)
+    cons.add_constraint(api.BoundConstraint(n, m, u_min=-pb.u_bnd, u_max=pb.u_bnd), (1, N - 1))
+    return api.Problem(model, obj, cons, x0=Xr[:, 0].copy(), N=N, U0=Ur.copy())
+
+
+class BatchMPC:
+    """Device-resident MPC loop over a RandomLinearBatch (reference run_MPC).
+
+    The long reference trajectory and the per-step noise samples are uploaded once; every
+    `step(i)` then runs entirely on the GPU in the reference's order:
+    plant step + 1 % noise -> x0; retarget tracking cost to window i+1; primal shift_fill;
+    dual shift_fill; solve  (random_linear_problem.jl:125-139,161).
+    """
+
+    def __init__(self, pb, opts=None, device=0):
+        self.pb = pb
+        self.solver = api.ALTROSolver(gen_tracking_problem(pb), opts or api.SolverOptions(**REF_OPTS), device)
+        s = self.solver
+        Xt, Ut = api._c(pb.Xtrack), api._c(pb.Utrack)
+        s._chk(s._L.altro_mpc_set_track(s.h, api._p(Xt), api._p(Ut), pb.Nt))
+        nz = api._c(pb.noise)
+        s._chk(s._L.altro_mpc_set_noise(s.h, api._p(nz), nz.shape[0]))
+        self.i = 0
+
+    def initial_solve(self):
+        """solve!(altro) before the loop (random_linear_problem.jl:113)."""
+        api.solve(self.solver)
+
+    def step_async(self, i=None):
+        i = self.i if i is None else i
+        s = self.solver
+        s._chk(s._L.altro_mpc_step_async(s.h, i))
+        self.i = i + 1
+
+    def synchronize(self):
+        s = self.solver
+        s._chk(s._L.altro_batch_synchronize(s.h))
+
+    def step(self, i=None):
+        self.step_async(i)
+        self.synchronize()
+
+    def x0(self):
+        s = self.solver
+        out = np.empty((s.B, s.n))
+        s._chk(s._L.altro_batch_get_initial_state(s.h, api._p(out)))
+        return out

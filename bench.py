@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC solves/sec, batched AL-iLQR run to tolerance, random_linear_mpc
+n=12 m=4 N=50 (BASELINE.json), batch 8192 per GPU.
+
+A "step" is one MPC step of the whole batch in the reference's order (plant step + 1 % noise,
+retarget the tracking cost, primal and dual shift_fill, warm-started solve;
+random_linear_problem.jl:121-161).  Every input of the timed region (long reference
+trajectories, noise samples, dynamics) is resident in HBM before the clock starts.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; instances are
+sharded over ranks (weak scaling: 8192 per GPU), there is no data-path collective, and the
+only RCCL traffic is one all_gather of the first controls after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+N_STATE, N_CTRL, N_KNOT = 12, 4, 50
+BATCH_PER_GPU = 8192
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector (= matrix) peak, datasheet; see DESIGN.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_backward(n, m, N):
+    """SURVEY.md 8(d)"""
+    return (N - 1) * (4 * n**3 + 8 * n**2 * m + 6 * n * m**2 + m**3 / 3 + 2 * n**2 + 8 * n * m + 4 * m**2)
+
+
+def flops_forward(n, m, N):
+    return (N - 1) * (2 * n**2 + 4 * n * m + 2 * (n + m)) + N * 3 * (n + m)
+
+
+def bytes_solve(n, m, N, p):
+    return 8 * ((n * n + n * m) + n + (N * n + (N - 1) * m) + (N - 1) * m + 2 * (N - 1) * p
+                + (N * n + (N - 1) * m) + 2 * (N - 1) * p + 12)
+
+
+def _cpu_worker(args):
+    """Run whole MPC loops of the oracle for ~budget seconds on one core."""
+    first, count, steps, budget = args
+    import altro_amd_loader  # noqa: F401
+    import altro_mpc_icra2021_amd as altro
+    import oracle_py
+    from helpers import make_oracle, mpc_update
+    pb = altro.problems.gen_random_linear_batch(count, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=steps, seed=1,
+                                                first_instance=first)
+    solves, t_solve = 0, 0.0
+    t_end = time.perf_counter() + budget
+    for b in range(count):
+        o = make_oracle(oracle_py, pb, b)
+        o.solve()
+        for i in range(steps):
+            mpc_update(o, pb, b, i)
+            t0 = time.perf_counter()
+            o.solve()
+            t_solve += time.perf_counter() - t0
+            solves += 1
+        if time.perf_counter() > t_end:
+            break
+    return solves, t_solve
+
+
+def cpu_baseline(budget_s=12.0):
+    """CPU restatement (the oracle, kind 'port') timed on this host's cores, same workload,
+    same options, one warm-started solve per MPC step (SURVEY 6.2 caveat).  Run BEFORE the GPU
+    is touched (process pool forks)."""
+    import multiprocessing as mp
+    cores = max(1, min(16, os.cpu_count() or 1))
+    steps = 40
+    per = 400  # instances offered to each worker; it stops when the time budget is spent
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(100000 + w * per, per, steps, budget_s) for w in range(cores)])
+    wall = time.perf_counter() - t0
+    solves = sum(r[0] for r in res)
+    t_solve = sum(r[1] for r in res)
+    return {
+        "value": solves / (t_solve / cores),          # solves/s with all `cores` busy (solve time only)
+        "unit": "solves/s",
+        "cores": cores,
+        "kind": "port",
+        "per_core": solves / t_solve,
+        "ms_per_solve_1core": 1e3 * t_solve / solves,
+        "sample": f"{solves} warm-started MPC solves (random_linear n=12 m=4 N=50, same options), "
+                  f"{cores} processes x whole MPC loops of {steps} steps, {wall:.1f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    import altro_amd_loader  # noqa: F401
+    import altro_mpc_icra2021_amd as altro
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, K, W = a.batch, a.steps, a.warmup
+    pb = altro.problems.gen_random_linear_batch(B, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=K + W, seed=1,
+                                                first_instance=rank * B)
+    mp = altro.mpc.BatchMPC(pb, device=local_rank)
+    mp.initial_solve()
+    for i in range(W):
+        mp.step(i)
+    altro.timing_reset(mp.solver)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        mp.step_async(i)
+    mp.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    st = altro.stats(mp.solver)
+    ms = altro.timing_get(mp.solver)
+    nb, nr = altro.work_counters(mp.solver)
+    ok = int((st.status == altro.SOLVE_SUCCEEDED).sum())
+
+    # final gather of the first controls (what an MPC consumer reads each tick)
+    U1 = torch.from_numpy(altro.controls(mp.solver)[:, 0].copy()).cuda()
+    if world > 1:
+        allU = torch.empty((world,) + tuple(U1.shape), dtype=U1.dtype, device="cuda")
+        dist.all_gather_into_tensor(allU, U1)
+        oks = torch.tensor([ok], device="cuda")
+        dist.all_reduce(oks)
+        ok = int(oks.item())
+
+    if rank == 0:
+        n, m, N = N_STATE, N_CTRL, N_KNOT
+        solves = world * B * K
+        value = solves / dt
+        # roofline of the dominant kernel (solve_kernel): algorithmic flops of one launch =
+        # sum over instances of the SURVEY 8(d) formula with the MEASURED pass counts
+        flops_launch = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N)) / max(1, len(ms))
+        avg_ms = float(ms.mean()) if len(ms) else float("nan")
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+        bytes_launch = B * bytes_solve(n, m, N, 2 * m)
+        out = {
+            "metric": "MPC solves/sec (batched iLQR to tol), random_linear_mpc n=12 m=4 N=50",
+            "value": value,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "random_linear_mpc n=12 m=4 N=50 batch=%d per GPU (BASELINE configs[1])" % B,
+                       "batch_per_gpu": B, "global_batch": world * B,
+                       "options": "tol 1e-4, penalty_initial 1000, penalty_scaling 100, reset_duals=false "
+                                  "(run_random_linear.jl:41-49)",
+                       "parallelism": "instances sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "altro::solve_kernel<12,4>", "avg_launch_ms": avg_ms, "launches": int(len(ms)),
+                         "note": "FP64 VALU (v_fmac_f64_dpp) path; MI355X FP64 vector peak = FP64 matrix peak",
+                         "hbm_algorithmic_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
+                         "hbm_frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "cpu_baseline": cpu,
+            "solve_succeeded_frac": ok / (world * B),
+            "iterations_mean": float(st.iterations.mean()),
+            "iterations_hist": np.bincount(st.iterations).tolist(),
+            "backward_passes_per_solve": float(nb.sum() / (B * K)),
+            "rollouts_per_solve": float(nr.sum() / (B * K)),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

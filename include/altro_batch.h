@@ -1,0 +1,214 @@
+/*
+ * altro_batch.h -- C-ABI of libaltro_hip.so: batched ALTRO (AL-iLQR) MPC solves on MI355X.
+ *
+ * The reference (RoboticExplorationLab/altro-mpc-icra2021) has no FFI: its benchmark scripts
+ * call the exported Julia API of Altro.jl / TrajectoryOptimization.jl / RobotDynamics.jl
+ * in-process.  Each entry point below replaces one of those calls for a BATCH of independent
+ * MPC instances; the reference call site it mirrors is cited (paths relative to the reference
+ * repo).  A Julia `ccall` shim over these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int32 (0 = ALTRO_OK); nothing throws or aborts across the ABI;
+ *     altro_last_error() returns a message for the last failing call of a handle (or of
+ *     altro_batch_create when called with NULL).
+ *   - solver failures are NOT errors: they are per-instance status values (enum below), as in
+ *     the reference (random_linear_problem.jl:166, altro_solver.jl:81).
+ *   - the caller owns every buffer it passes; the library copies in/out and keeps no caller
+ *     pointer after return (Julia's GC may move or free them).
+ *   - host arrays are instance-major: X is [batch][N][n], U is [batch][N-1][m]; matrices are
+ *     COLUMN-major n x n / n x m blocks (Julia layout).
+ *   - a handle is single-owner (not thread-safe) and owns one HIP stream and all its device
+ *     memory.  Different handles may be driven from different threads.
+ *   - all arithmetic is FP64, as in the reference.
+ */
+#ifndef ALTRO_BATCH_H
+#define ALTRO_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  ALTRO_OK = 0,
+  ALTRO_ERR_INVALID_ARG = 1,
+  ALTRO_ERR_UNSUPPORTED = 2, /* problem shape/constraint outside the built kernel set */
+  ALTRO_ERR_HIP = 3,         /* HIP runtime failure (message has the HIP error string) */
+  ALTRO_ERR_STATE = 4        /* call sequence error (e.g. solve before set_dynamics) */
+};
+
+/* Altro.TerminationStatus.  Only UNSOLVED and SOLVE_SUCCEEDED are named in the reference
+ * (simple_rocket.jl:144, random_linear_problem.jl:166); order restated from Altro.jl v0.2. */
+enum {
+  ALTRO_UNSOLVED = 0,
+  ALTRO_SOLVE_SUCCEEDED = 1,
+  ALTRO_MAX_ITERATIONS = 2,
+  ALTRO_MAX_ITERATIONS_OUTER = 3,
+  ALTRO_MAXIMUM_COST = 4,
+  ALTRO_STATE_LIMIT = 5,
+  ALTRO_CONTROL_LIMIT = 6,
+  ALTRO_NO_PROGRESS = 7,
+  ALTRO_COST_INCREASE = 8
+};
+
+/* constraint menu: user constraint types of the reference are Julia closures
+ * (new_constraints.jl:31-62), which cannot cross a C ABI; they are all affine maps of
+ * z = [x;u] into {=0, <=0, second-order cone} and are passed as data. */
+enum { ALTRO_CON_BOX = 0, ALTRO_CON_LINEAR = 1, ALTRO_CON_SOC = 2 };
+enum { ALTRO_SENSE_EQ = 0, ALTRO_SENSE_INEQ = 1 };
+
+typedef struct altro_dims {
+  int32_t batch; /* number of independent MPC instances */
+  int32_t n;     /* state dimension   */
+  int32_t m;     /* control dimension */
+  int32_t N;     /* knot points       */
+} altro_dims;
+
+/* Altro.SolverOptions: fields the reference sets (run_random_linear.jl:41-49,
+ * run_simple_rocket.jl:39-50, grasp_benchmark.jl:19-34, ALTROParams.jl:86-95) plus the
+ * iLQR/AL internals they rely on.  altro_default_opts() fills Altro.jl's defaults. */
+typedef struct altro_opts {
+  double cost_tolerance;
+  double cost_tolerance_intermediate;
+  double gradient_tolerance;
+  double gradient_tolerance_intermediate;
+  double constraint_tolerance;
+  double penalty_initial;  /* NaN = per-constraint default (1.0) */
+  double penalty_scaling;  /* NaN = per-constraint default (10)  */
+  double penalty_max;
+  double dual_max;
+  double line_search_lower_bound;
+  double line_search_upper_bound;
+  double max_cost_value;
+  double max_state_value;
+  double max_control_value;
+  double bp_reg_initial;
+  double bp_reg_increase_factor;
+  double bp_reg_max;
+  double bp_reg_min;
+  double bp_reg_fp;
+  int32_t iterations;
+  int32_t iterations_inner;
+  int32_t iterations_outer;
+  int32_t iterations_linesearch;
+  int32_t dJ_counter_limit;
+  int32_t reset_duals;
+  int32_t reset_penalties;
+  int32_t bp_reg;
+  int32_t soc_second_order;
+} altro_opts;
+
+#define ALTRO_TRACE_LEN 16 /* per-instance trace depth kept on device */
+
+typedef struct altro_handle altro_handle;
+
+/* SolverOptions() defaults */
+int32_t altro_default_opts(altro_opts* opts);
+
+/* ALTROSolver(prob, opts): random_linear_problem.jl:87, simple_rocket.jl:128,
+ * grasp_mpc.jl:35, ALTROParams.jl:96.  Allocates every device workspace. */
+int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32_t device,
+                           altro_handle** out);
+int32_t altro_batch_destroy(altro_handle* h);
+const char* altro_last_error(const altro_handle* h);
+
+/* RD.LinearModel(A, B[, d]; dt): random_linear_problem.jl:8; LTV/affine: ALTROParams.jl:61,
+ * linearized_dynamics.jl:69-96.   x+ = A x + B u + f.
+ *   per_instance != 0: arrays hold `batch` blocks, else one block shared by all instances
+ *   per_knot     != 0: each block holds N-1 knot blocks (LTV)
+ * f may be NULL (zero). */
+int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
+                                 int32_t per_knot, int32_t per_instance);
+
+/* TO.TrackingObjective(Q, R, Z; Qf) / LQRObjective with diagonal weights: mpc.jl:26-29.
+ * Stage costs are scaled by dt, the terminal cost is not (random_linear_problem.jl:52-53). */
+int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qdiag, const double* Rdiag,
+                                      const double* Qfdiag, double dt);
+
+/* add_constraint!(cons, con, inds): random_linear_problem.jl:23-24 (BoundConstraint),
+ * rocket_landing_problem.jl:96,123-124,142,165, grasp_problem.jl:29-67, ALTROParams.jl:67-78.
+ *   k_first..k_last: 0-based inclusive knot range (knot N-1 is terminal: state columns only)
+ *   BOX:    zmin, zmax of length n+m (+-inf = absent)
+ *   LINEAR: A [p][n+m] ROW-major, b [p]; value A z + b {= 0 | <= 0}
+ *   SOC:    A, b as above; value v = A z + b with ||v[0..p-2]|| <= v[p-1]
+ *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67)
+ * Constraint data is shared by all instances of the batch. */
+int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first,
+                                   int32_t k_last, int32_t p, const double* A, const double* b,
+                                   const double* zmin, const double* zmax, int32_t per_knot,
+                                   int32_t* con_id);
+/* in-place mutation of per-knot constraint data: grasp_mpc_helpers.jl:46-55 */
+int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A,
+                                           const double* b);
+
+/* TO.set_initial_state!: random_linear_problem.jl:130.  x0 is [batch][n]. */
+int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0);
+/* TO.update_trajectory!(obj, Z_track, k): random_linear_problem.jl:133.
+ * Xref [batch][N][n], Uref [batch][N-1][m]. */
+int32_t altro_batch_set_reference(altro_handle* h, const double* Xref, const double* Uref);
+/* initial_trajectory! / initial_controls! / initial_states!: mpc.jl:45, altro_solver.jl:70-71.
+ * X may be NULL (iLQR re-rolls the states out from x0). */
+int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, const double* U);
+/* RD.shift_fill!(Z) and Altro.shift_fill!(conSet): random_linear_problem.jl:136,139 */
+int32_t altro_batch_shift_fill(altro_handle* h, int32_t shift_primal, int32_t shift_dual);
+/* set_options!: flexible_sat_mpc.jl:163 */
+int32_t altro_batch_set_options(altro_handle* h, const altro_opts* opts);
+
+/* solve!(solver): random_linear_problem.jl:113.  Synchronous on return. */
+int32_t altro_batch_solve(altro_handle* h);
+/* Same, but only enqueued on the handle's stream; pair with altro_batch_synchronize. */
+int32_t altro_batch_solve_async(altro_handle* h);
+int32_t altro_batch_synchronize(altro_handle* h);
+
+/* states(solver), controls(solver), Altro.get_duals: random_linear_problem.jl:177-181 */
+int32_t altro_batch_get_states(altro_handle* h, double* X);
+int32_t altro_batch_get_controls(altro_handle* h, double* U);
+/* duals of one constraint: BOX -> [batch][nk][2][n+m] (upper rows, then lower rows),
+ * LINEAR/SOC -> [batch][nk][p] */
+int32_t altro_batch_get_duals(altro_handle* h, int32_t con_id, double* lambda);
+int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lambda);
+
+/* iterations(solver), status(solver), cost(solver), max_violation(solver), solver.stats:
+ * random_linear_problem.jl:166-174.  Any output pointer may be NULL.  Arrays have `batch`
+ * entries; traces are [batch][ALTRO_TRACE_LEN] (cost and max violation after each of the
+ * first ALTRO_TRACE_LEN iLQR iterations). */
+int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* iterations_outer,
+                              int32_t* status, double* cost, double* c_max, double* cost_trace,
+                              double* cmax_trace);
+/* device time of the last solve launch sequence on the handle's stream, HIP events (ms) */
+int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms);
+/* Launch-duration history of the solve kernel (HIP events recorded on the handle's stream around
+ * every solve launch since the last reset): the measurement behind bench.py's roofline figure.
+ * reset also clears the work counters below.  Synchronises the stream. */
+int32_t altro_batch_timing_reset(altro_handle* h);
+int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count);
+/* Work done since the last timing reset, per instance: iLQR backward passes and rollouts
+ * (open-loop + line-search trials).  These are the measured counts SURVEY 8(d)'s flops_solve
+ * formula is evaluated with.  Arrays of `batch` int64. */
+int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts);
+
+/* ---- device-resident MPC harness (reference random_linear_problem.jl:121-139, mpc.jl:11-47).
+ * The reference's MPC loop runs on the host around solve!; for a batch that lives in HBM the
+ * same update sequence is provided on device so that no step crosses PCIe. */
+
+/* Long reference trajectory Z_track (run_random_linear.jl:111-112): Xtrack [batch][Nt][n],
+ * Utrack [batch][Nt-1][m].  Also installs window 0 as reference and initial trajectory
+ * (gen_tracking_problem, mpc.jl:19-45). */
+int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double* Utrack, int32_t Nt);
+/* unit-normal samples for the 1 % plant noise (random_linear_problem.jl:129): [steps][batch][n] */
+int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps);
+/* One MPC step i (0-based), enqueued on the handle's stream, in the reference's order
+ * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
+ * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */
+int32_t altro_mpc_step_async(altro_handle* h, int32_t step);
+/* x0 currently installed: [batch][n] */
+int32_t altro_batch_get_initial_state(altro_handle* h, double* x0);
+
+/* the handle's hipStream_t, for callers that order their own device work after a solve */
+int32_t altro_batch_get_stream(altro_handle* h, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/altro_batch.h declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import altro_mpc_icra2021_amd as altro
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    altro._lib.build()
+    return altro._lib.lib()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "altro_batch.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(altro_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(lib):
+    syms = header_symbols()
+    assert sorted(altro._lib.EXPORTS) == syms
+    for s in syms:
+        assert hasattr(lib, s), f"libaltro_hip.so does not export {s}"
+
+
+def test_default_opts_match_altro_defaults(lib):
+    o = altro.SolverOptions()
+    assert o.cost_tolerance == 1e-4 and o.constraint_tolerance == 1e-6
+    assert o.iterations_inner == 300 and o.iterations_outer == 30 and o.iterations_linesearch == 20
+    assert o.reset_duals == 1 and o.reset_penalties == 1
+    assert o.penalty_initial != o.penalty_initial  # NaN = per-constraint default
+    o2 = altro.SolverOptions(**altro.mpc.REF_OPTS, projected_newton=False)
+    assert o2.penalty_initial == 1000.0 and o2.reset_duals == 0
+    with pytest.raises(KeyError):
+        altro.SolverOptions(no_such_option=1)
+
+
+def test_opts_struct_layout_matches_header(lib):
+    txt = open(os.path.join(ROOT, "include", "altro_batch.h")).read()
+    body = txt[txt.index("typedef struct altro_opts {"):txt.index("} altro_opts;")]
+    fields = re.findall(r"^\s*(double|int32_t)\s+(\w+);", body, flags=re.M)
+    assert [f for _, f in fields] == [f for f, _ in altro._lib.Opts._fields_]
+    for (ctype, name), (_, pyt) in zip(fields, altro._lib.Opts._fields_):
+        assert (ctype == "double") == (pyt is C.c_double)
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pb = altro.problems.gen_random_linear_batch(2, steps=1)
+    with pytest.raises(altro.AltroError) as e:
+        altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
+    assert e.value.code == altro._lib.ERR_HIP
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "altro-mpc-icra2021_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                src = open(os.path.join(dirpath, f)).read()
+                # comments may cite the oracle as the parity reference; code may not use it
+                assert not re.search(r"^\s*(import|from)\s+\S*oracle", src, flags=re.M), f
+                assert not re.search(r"#include\s+\S*oracle", src), f
+                assert "oracle_py" not in src and "libaltro_oracle" not in src, f

@@ -1,0 +1,174 @@
+"""GPU parity tests (run by the driver with -m gpu on a real MI355X): the HIP path, reached
+through the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances: the brief (BASELINE.json north_star) asks for cost / constraint-violation
+trajectories within 1e-6 relative; RTOL below is that number.  Integer outputs (iteration
+counts, status) must be equal.  At BASELINE's full batch (8192) the oracle cannot run every
+instance in seconds, so a strided sample is compared and the whole batch is checked through
+size-independent properties (bounds respected, dynamics feasibility, x_1 == x0 exactly, every
+status SOLVE_SUCCEEDED, instance i identical whatever the batch around it).
+"""
+import numpy as np
+import pytest
+
+import altro_mpc_icra2021_amd as altro
+from helpers import REF_OPTS, make_oracle, mpc_update
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def check_against_oracle(st, X, U, b, orc, so):
+    assert int(st.status[b]) == so.status
+    assert int(st.iterations[b]) == so.iterations
+    assert int(st.iterations_outer[b]) == so.iterations_outer
+    assert abs(st.cost[b] - so.cost) <= RTOL * max(1.0, abs(so.cost))
+    assert abs(st.c_max[b] - so.c_max) <= RTOL * max(1.0, abs(so.c_max))
+    k = min(so.iterations, altro._lib.TRACE_LEN)
+    Jo = np.array(so.J[:k])
+    co = np.array(so.cmax_it[:k])
+    assert np.all(np.abs(st.cost_trace[b, :k] - Jo) <= RTOL * np.maximum(1.0, np.abs(Jo)))
+    assert np.all(np.abs(st.cmax_trace[b, :k] - co) <= RTOL * np.maximum(1.0, np.abs(co)))
+    assert rel_err(X[b], orc.states()) <= RTOL
+    assert rel_err(U[b], orc.controls()) <= RTOL
+
+
+@pytest.mark.parametrize("n,m,N", [(12, 4, 50), (6, 3, 21), (6, 6, 31), (8, 4, 11)])
+def test_mpc_loop_matches_oracle(oracle, n, m, N):
+    """Warm-started MPC loop (reference run_MPC order) for every built kernel size."""
+    B, S = 10, 8   # B not a multiple of 4: exercises the padded instance slots
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=11)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    sos = [o.solve() for o in orcs]
+    st = altro.stats(mp.solver)
+    X, U = altro.states(mp.solver), altro.controls(mp.solver)
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], sos[b])
+    for i in range(S):
+        mp.step(i)
+        st = altro.stats(mp.solver)
+        X, U = altro.states(mp.solver), altro.controls(mp.solver)
+        x0g = mp.x0()
+        for b in range(B):
+            x0 = mpc_update(orcs[b], pb, b, i)
+            assert np.abs(x0 - x0g[b]).max() <= 1e-12 * max(1.0, np.abs(x0).max())
+            so = orcs[b].solve()
+            check_against_oracle(st, X, U, b, orcs[b], so)
+            assert np.array_equal(X[b, 0], x0g[b])  # :err_x0 of the reference is identically 0
+
+
+def test_cold_solve_far_from_reference_matches_oracle(oracle):
+    """Cold solves from a perturbed initial state: many active bounds, several AL outer
+    iterations, line-search activity."""
+    B = 12
+    pb = altro.problems.gen_random_linear_batch(B, steps=1, seed=21)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    rng = np.random.default_rng(0)
+    prob.x0 = prob.x0 + rng.standard_normal(prob.x0.shape) * np.linspace(0.5, 8.0, B)[:, None]
+    opts = dict(REF_OPTS, reset_duals=1, constraint_tolerance=1e-6, cost_tolerance=1e-6,
+                cost_tolerance_intermediate=1e-6, penalty_scaling=10.0)
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**opts))
+    altro.solve(sv)
+    st = altro.stats(sv)
+    X, U = altro.states(sv), altro.controls(sv)
+    nout = 0
+    for b in range(B):
+        o = make_oracle(oracle, pb, b, opts=opts)
+        o.set_initial_state(prob.x0[b])
+        so = o.solve()
+        nout = max(nout, so.iterations_outer)
+        check_against_oracle(st, X, U, b, o, so)
+        # duals
+        lam = altro.get_duals(sv)[b]           # (nk, 2, nz)
+        assert np.abs(lam.reshape(-1) - o.duals(0)).max() <= RTOL * max(1.0, np.abs(o.duals(0)).max())
+    assert nout >= 2, "test must exercise the AL outer loop"
+
+
+def test_unconstrained_problem(oracle):
+    B = 4
+    pb = altro.problems.gen_random_linear_batch(B, n=8, m=4, N=15, steps=1, seed=4)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.constraints.items.clear()
+    prob.x0 = prob.x0 + 1.0
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**REF_OPTS))
+    altro.solve(sv)
+    st = altro.stats(sv)
+    X, U = altro.states(sv), altro.controls(sv)
+    for b in range(B):
+        o = make_oracle(oracle, pb, b, bounded=False)
+        o.set_initial_state(prob.x0[b])
+        so = o.solve()
+        check_against_oracle(st, X, U, b, o, so)
+
+
+def test_full_batch_properties_and_sampled_parity(oracle):
+    """BASELINE config 2: n=12, m=4, N=50, batch 8192."""
+    B, S = 8192, 3
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=1)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    sample = list(range(0, B, 683)) + [B - 1]
+    orcs = {b: make_oracle(oracle, pb, b) for b in sample}
+    for o in orcs.values():
+        o.solve()
+    for i in range(S):
+        mp.step(i)
+        st = altro.stats(mp.solver)
+        X, U = altro.states(mp.solver), altro.controls(mp.solver)
+        x0 = mp.x0()
+        assert np.all(st.status == altro.SOLVE_SUCCEEDED)
+        assert np.median(st.iterations) == 2
+        assert np.abs(U).max() <= pb.u_bnd + 1e-4          # constraint_tolerance of the run
+        assert np.array_equal(X[:, 0], x0)
+        Xn = np.einsum("bij,bkj->bki", pb.A, X[:, :-1]) + np.einsum("bij,bkj->bki", pb.Bm, U)
+        assert np.abs(Xn - X[:, 1:]).max() <= 1e-11 * max(1.0, np.abs(X).max())
+        for b, o in orcs.items():
+            mpc_update(o, pb, b, i)
+            so = o.solve()
+            check_against_oracle(st, X, U, b, o, so)
+
+
+def test_instance_results_do_not_depend_on_batch(oracle):
+    """Instances are independent: instance i gives bit-identical results alone or in a batch."""
+    pb = altro.problems.gen_random_linear_batch(9, steps=2, seed=8)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    mp.step(0)
+    Xall = altro.states(mp.solver)
+    pb1 = altro.problems.gen_random_linear_batch(1, steps=2, seed=8, first_instance=5)
+    mp1 = altro.mpc.BatchMPC(pb1)
+    mp1.initial_solve()
+    mp1.step(0)
+    assert np.array_equal(altro.states(mp1.solver)[0], Xall[5])
+
+
+def test_shift_fill_and_accessors_roundtrip():
+    B = 5
+    pb = altro.problems.gen_random_linear_batch(B, n=6, m=3, N=9, steps=1, seed=2)
+    sv = altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb), altro.SolverOptions(**REF_OPTS))
+    rng = np.random.default_rng(1)
+    U = rng.standard_normal((B, 8, 3))
+    altro.initial_controls(sv, U)
+    assert np.array_equal(altro.controls(sv), U)
+    lam = rng.random((B, 8, 2, 9))
+    altro.set_duals(sv, lam)
+    assert np.array_equal(altro.get_duals(sv), lam)
+    altro.shift_fill(sv, True, True)
+    Us = altro.controls(sv)
+    assert np.array_equal(Us[:, :-1], U[:, 1:]) and np.array_equal(Us[:, -1], U[:, -1])
+    ls = altro.get_duals(sv)
+    assert np.array_equal(ls[:, :-1], lam[:, 1:]) and np.array_equal(ls[:, -1], lam[:, -1])
+
+
+def test_error_paths():
+    pb = altro.problems.gen_random_linear_batch(2, n=5, m=2, N=9, steps=1)
+    with pytest.raises(altro.AltroError) as e:
+        altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
+    assert e.value.code == altro._lib.ERR_UNSUPPORTED
