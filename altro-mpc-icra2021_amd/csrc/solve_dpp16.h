@@ -575,7 +575,7 @@ struct Solver {
       // ---------------- AL outer update
       bool upd = false;
       if (alive) {
-        iters_outer++;
+        if (has_con) iters_outer++;
         if (!has_con) {
           if (status == ALTRO_UNSOLVED) status = ALTRO_SOLVE_SUCCEEDED;
           cmax = 0.0;
