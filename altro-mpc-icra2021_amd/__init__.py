@@ -10,5 +10,5 @@ from ._lib import SOLVE_SUCCEEDED, STATUS_NAMES  # noqa: F401
 from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, LinearModel, Problem,  # noqa: F401
                   SolverOptions, TrackingObjective, controls, cost, get_duals, initial_controls,
                   iterations, max_violation, set_duals, set_initial_state, set_options, shift_fill,
-                  solve, states, stats, status, timing_get, timing_reset, update_trajectory,
-                  work_counters)
+                  solve, solve_counters, states, stats, status, timing_get, timing_reset, update_trajectory,
+                  wave_cycles, work_counters)

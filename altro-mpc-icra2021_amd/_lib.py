@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libaltro_hip.so")
+LIB_PATH = os.environ.get("ALTRO_HIP_LIB") or os.path.join(CSRC, "libaltro_hip.so")
 
 TRACE_LEN = 16
 
@@ -30,7 +30,8 @@ EXPORTS = [
     "altro_batch_synchronize", "altro_batch_get_states", "altro_batch_get_controls",
     "altro_batch_get_duals", "altro_batch_set_duals", "altro_batch_get_stats",
     "altro_batch_last_solve_ms", "altro_batch_timing_reset", "altro_batch_timing_get",
-    "altro_batch_get_work_counters", "altro_mpc_set_track", "altro_mpc_set_noise",
+    "altro_batch_get_work_counters", "altro_batch_get_wave_cycles", "altro_batch_get_solve_counters", "altro_mpc_run_async",
+    "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
 ]
 """every symbol include/altro_batch.h declares"""
@@ -115,7 +116,11 @@ def lib():
     L.altro_batch_last_solve_ms.argtypes = [H, C.POINTER(C.c_float)]
     L.altro_batch_timing_reset.argtypes = [H]
     L.altro_batch_timing_get.argtypes = [H, C.POINTER(C.c_float), C.c_int32, ip]
-    L.altro_batch_get_work_counters.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.altro_batch_get_work_counters.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.altro_batch_get_wave_cycles.argtypes = [H, C.POINTER(C.c_int64), C.c_int32, ip]
+    i64 = C.POINTER(C.c_int64)
+    L.altro_batch_get_solve_counters.argtypes = [H, i64, i64, i64]
+    L.altro_mpc_run_async.argtypes = [H, C.c_int32, C.c_int32]
     L.altro_mpc_set_track.argtypes = [H, dp, dp, C.c_int32]
     L.altro_mpc_set_noise.argtypes = [H, dp, C.c_int32]
     L.altro_mpc_step_async.argtypes = [H, C.c_int32]

@@ -302,9 +302,27 @@ def timing_get(solver):
 
 
 def work_counters(solver):
-    """(backward passes, rollouts) per instance since timing_reset."""
-    nb = np.zeros(solver.B, dtype=np.int64)
-    nr = np.zeros(solver.B, dtype=np.int64)
-    solver._chk(solver._L.altro_batch_get_work_counters(
-        solver.h, nb.ctypes.data_as(C.POINTER(C.c_int64)), nr.ctypes.data_as(C.POINTER(C.c_int64))))
-    return nb, nr
+    """(backward passes, rollouts, interpolated line-search trials) per instance since
+    timing_reset."""
+    i64 = C.POINTER(C.c_int64)
+    a = [np.zeros(solver.B, dtype=np.int64) for _ in range(3)]
+    solver._chk(solver._L.altro_batch_get_work_counters(solver.h, *[x.ctypes.data_as(i64) for x in a]))
+    return tuple(a)
+
+
+def wave_cycles(solver):
+    """(waves, 8) s_memtime ticks of the last solve launch per wave: total, backward, closed
+    rollouts, open rollouts, Todorov gradient, dual update (diagnostic)."""
+    cnt = C.c_int32(0)
+    solver._chk(solver._L.altro_batch_get_wave_cycles(solver.h, None, 0, C.byref(cnt)))
+    out = np.zeros(cnt.value, dtype=np.int64)
+    solver._chk(solver._L.altro_batch_get_wave_cycles(solver.h, out.ctypes.data_as(C.POINTER(C.c_int64)), cnt.value, C.byref(cnt)))
+    return out.reshape(-1, 8)
+
+
+def solve_counters(solver):
+    """(solves, iLQR iterations, SOLVE_SUCCEEDED count) per instance since timing_reset."""
+    i64 = C.POINTER(C.c_int64)
+    a = [np.zeros(solver.B, dtype=np.int64) for _ in range(3)]
+    solver._chk(solver._L.altro_batch_get_solve_counters(solver.h, *[x.ctypes.data_as(i64) for x in a]))
+    return tuple(a)

@@ -31,7 +31,8 @@ struct altro_handle {
   bool timed = false;
   std::vector<hipEvent_t> hist;  // start/end event pairs of solve launches since the last reset
   size_t hist_used = 0;
-  long long *n_backward = nullptr, *n_rollout = nullptr;
+  long long *n_backward = nullptr, *n_rollout = nullptr, *wave_cycles = nullptr;
+  long long *n_solves = nullptr, *n_iters = nullptr, *n_ok = nullptr, *n_trials = nullptr;
   // problem data (device)
   double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
@@ -229,25 +230,6 @@ __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, si
   }
 }
 
-// Plant step of the MPC loop (random_linear_problem.jl:128-130):
-//   x0 <- A x_1 + B u_1 + f + randn(n) * ||x0||_inf / 100
-// one 16-lane group per instance; noise are unit normals supplied by the caller.
-__global__ void k_plant_step(const double* __restrict__ Zp, const int* __restrict__ cur, size_t plane,
-                             const double* __restrict__ Grow, const double* __restrict__ fvec,
-                             const double* __restrict__ noise, double* __restrict__ x0, int B, int Bp, int n) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= Bp * LW) return;
-  const int inst = t / LW, j = t % LW;
-  const int b = inst < B ? inst : B - 1;
-  const double* z0 = Zp + (size_t)cur[inst] * plane + (size_t)inst * LW;  // knot 0
-  double acc = fvec[(size_t)inst * LW + j];
-  for (int c = 0; c < LW; ++c) acc += Grow[((size_t)inst * LW + c) * LW + j] * z0[c];
-  double a = j < n ? fabs(acc) : 0.0;
-  for (int s = 8; s >= 1; s >>= 1) a = fmax(a, __shfl_xor(a, s, LW));
-  const double nz = (noise && j < n) ? noise[(size_t)b * n + j] : 0.0;
-  x0[(size_t)inst * LW + j] = j < n ? acc + nz * a / 100.0 : 0.0;
-}
-
 __global__ void k_fill(double* p, double v, size_t nelem) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nelem) p[t] = v;
@@ -260,10 +242,12 @@ static bool supported_dims(int n, int m) {
   return (n == 12 && m == 4) || (n == 6 && m == 3) || (n == 6 && m == 6) || (n == 8 && m == 4);
 }
 
-static int launch_solve(altro_handle* h) {
+static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   altro::SolveParams p{};
   p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
   p.kref = h->kref;
+  p.first_step = first_step; p.nsteps = nsteps;
+  p.noise = h->noise;
   p.box_k0 = h->box_k0; p.box_k1 = h->box_k1;
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
@@ -271,7 +255,8 @@ static int launch_solve(altro_handle* h) {
   p.Lhi = h->Lhi; p.Llo = h->Llo; p.mu = h->mu; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace;
-  p.n_backward = h->n_backward; p.n_rollout = h->n_rollout;
+  p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
+  p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
   p.o = h->o;
   const dim3 grid(h->Bp / IPW), block(64);
   const int n = h->d.n, m = h->d.m;
@@ -367,6 +352,12 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipEventCreate(&h->ev1));
   const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
   const size_t row = Bp * LW;
+  // the kernels address every array with 32-bit element offsets
+  if (2 * N * row * sizeof(double) >= (1ull << 32) || (N - 1) * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
+    g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
+    altro_batch_destroy(h);
+    return ALTRO_ERR_UNSUPPORTED;
+  }
   CCHK(hipMalloc(&h->Gcol, Bp * n * LW * sizeof(double)));
   CCHK(hipMalloc(&h->Grow, Bp * LW * LW * sizeof(double)));
   CCHK(hipMalloc(&h->fvec, row * sizeof(double)));
@@ -390,6 +381,16 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMalloc(&h->ctrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
   CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
   CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
+  CCHK(hipMalloc(&h->wave_cycles, Bp * 2 * sizeof(long long)));
+  CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
+  CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
+  CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
+  CCHK(hipMalloc(&h->n_trials, Bp * sizeof(long long)));
+  CCHK(hipMemsetAsync(h->n_trials, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
+  CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 2 * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->Z, 0, 2 * N * row * sizeof(double), h->stream));
@@ -426,7 +427,7 @@ int32_t altro_batch_destroy(altro_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lhi, h->Llo,
                   h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
-                  h->ctrace, h->stage, h->n_backward, h->n_rollout};
+                  h->ctrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : h->hist) hipEventDestroy(e);
@@ -537,6 +538,7 @@ static int set_ref_common(altro_handle* h, const double* Xref, const double* Ure
   const size_t cx = B * Nt * n, cu = B * (Nt - 1) * m;
   int rc = ensure_stage(h, (cx + cu) * sizeof(double));
   if (rc) return rc;
+  if ((size_t)Nt * h->Bp * LW * sizeof(double) >= (1ull << 32)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "reference trajectory too large for one handle (below 4 GiB)");
   if (h->Nt != Nt) {
     if (h->Zref) HIPCHK(h, hipFree(h->Zref));
     h->Zref = nullptr;
@@ -593,18 +595,13 @@ int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
   return ALTRO_OK;
 }
 
-int32_t altro_batch_solve_async(altro_handle* h) {
-  if (!h) return ALTRO_ERR_INVALID_ARG;
+static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = check_ready(h);
   if (rc) return rc;
-  if (h->kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
+  const int last_kref = nsteps > 0 ? first_step + nsteps : h->kref;
+  if (last_kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  if (h->o.reset_duals && h->box_k1 >= h->box_k0) {
-    const size_t bytes = (size_t)h->d.N * h->Bp * LW * sizeof(double);
-    HIPCHK(h, hipMemsetAsync(h->Lhi, 0, bytes, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->Llo, 0, bytes, h->stream));
-  }
   if (h->hist_used + 2 > h->hist.size()) {
     for (int i = 0; i < 2; ++i) {
       hipEvent_t e;
@@ -613,13 +610,19 @@ int32_t altro_batch_solve_async(altro_handle* h) {
     }
   }
   HIPCHK(h, hipEventRecord(h->hist[h->hist_used], h->stream));
-  rc = launch_solve(h);
+  rc = launch_solve(h, first_step, nsteps);
   if (rc) return rc;
   HIPCHK(h, hipEventRecord(h->hist[h->hist_used + 1], h->stream));
   h->hist_used += 2;
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
+  if (nsteps > 0) h->kref = first_step + nsteps;
   return ALTRO_OK;
+}
+
+int32_t altro_batch_solve_async(altro_handle* h) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  return enqueue_solve(h, 0, 0);
 }
 
 int32_t altro_batch_synchronize(altro_handle* h) {
@@ -720,6 +723,10 @@ int32_t altro_batch_timing_reset(altro_handle* h) {
   h->hist_used = 0;
   HIPCHK(h, hipMemsetAsync(h->n_backward, 0, h->Bp * sizeof(long long), h->stream));
   HIPCHK(h, hipMemsetAsync(h->n_rollout, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->n_solves, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->n_iters, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->n_ok, 0, h->Bp * sizeof(long long), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->n_trials, 0, h->Bp * sizeof(long long), h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return ALTRO_OK;
 }
@@ -735,13 +742,35 @@ int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int
   return ALTRO_OK;
 }
 
-int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts) {
+int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t B = h->d.batch;
+  if (solves) HIPCHK(h, hipMemcpy(solves, h->n_solves, B * sizeof(long long), hipMemcpyDeviceToHost));
+  if (iterations) HIPCHK(h, hipMemcpy(iterations, h->n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
+  if (succeeded) HIPCHK(h, hipMemcpy(succeeded, h->n_ok, B * sizeof(long long), hipMemcpyDeviceToHost));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts, int64_t* trials) {
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const size_t B = h->d.batch;
   if (backward_passes) HIPCHK(h, hipMemcpy(backward_passes, h->n_backward, B * sizeof(long long), hipMemcpyDeviceToHost));
   if (rollouts) HIPCHK(h, hipMemcpy(rollouts, h->n_rollout, B * sizeof(long long), hipMemcpyDeviceToHost));
+  if (trials) HIPCHK(h, hipMemcpy(trials, h->n_trials, B * sizeof(long long), hipMemcpyDeviceToHost));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t capacity, int32_t* count) {
+  if (!h || !count) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int32_t n = h->Bp / IPW * 8;
+  *count = n;
+  if (cycles) HIPCHK(h, hipMemcpy(cycles, h->wave_cycles, (size_t)(n < capacity ? n : capacity) * sizeof(long long), hipMemcpyDeviceToHost));
   return ALTRO_OK;
 }
 
@@ -783,27 +812,15 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
   return ALTRO_OK;
 }
 
-int32_t altro_mpc_step_async(altro_handle* h, int32_t step) {
+int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps) {
   if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  int rc = check_ready(h);
-  if (rc) return rc;
-  if (step < 0 || (h->noise && step >= h->noise_steps)) FAIL(h, ALTRO_ERR_INVALID_ARG, "step outside the uploaded noise");
-  if (step + 1 + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "step runs past the end of the track");
-  const size_t plane = (size_t)h->d.N * h->Bp * LW;
-  const double* nz = h->noise ? h->noise + (size_t)step * h->d.batch * h->d.n : nullptr;
-  // x0 <- plant(x_1, u_1) + noise          (random_linear_problem.jl:128-130)
-  hipLaunchKernelGGL(k_plant_step, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Grow,
-                     h->fvec, nz, h->x0, h->d.batch, h->Bp, h->d.n);
-  HIPCHK(h, hipGetLastError());
-  // update_trajectory!(obj, Z_track, k_mpc)  (random_linear_problem.jl:133)
-  h->kref = step + 1;
-  // shift_fill! primal then dual             (random_linear_problem.jl:136,139)
-  rc = altro_batch_shift_fill(h, 1, 1);
-  if (rc) return rc;
-  // solve!                                   (random_linear_problem.jl:161)
-  return altro_batch_solve_async(h);
+  if (nsteps < 1 || first_step < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad step range");
+  if (h->noise && first_step + nsteps > h->noise_steps) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps outside the uploaded noise");
+  if (first_step + nsteps + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps run past the end of the track");
+  return enqueue_solve(h, first_step, nsteps);
 }
+
+int32_t altro_mpc_step_async(altro_handle* h, int32_t step) { return altro_mpc_run_async(h, step, 1); }
 
 int32_t altro_batch_get_stream(altro_handle* h, void** stream) {
   if (!h || !stream) return ALTRO_ERR_INVALID_ARG;

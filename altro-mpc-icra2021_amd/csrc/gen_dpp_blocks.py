@@ -76,13 +76,23 @@ def gen(NX, NU):
         [(f"k{a}", f"kd[{a}]") for a in range(NU)] + [(f"t{a}", f"T[{a}]") for a in range(NU)] +
         [(f"r{a}", f"r[{a}]") for a in range(NU)]))
 
-    # ---- KDX: du_p += sum_{j in part p} bcast_j(dx) * krow[j]   (3 partial sums, j < NX)
-    NP = 3
-    body = [fmac(f"a{j % NP}", "dx", f"k{j}", j) for j in range(NX)]
+    # ---- CTG0: h[i] += sum_a bcast_i(r[a]) * kd[a]   (the rho == 0 case: S = Qxx + Qux' K)
+    body = []
+    for a in range(NU):
+        body += [fmac(f"h{i}", f"r{a}", f"k{a}", i) for i in range(NX)]
     out.append(emit_block(
-        "KDX", f"double (&acc)[{NP}], const double& dx, const double (&krow)[{NX}]", body,
-        [(f"a{p}", f"acc[{p}]") for p in range(NP)],
-        [("dx", "dx")] + [(f"k{j}", f"krow[{j}]") for j in range(NX)]))
+        "CTG0", f"double (&h)[{NZ}], const double (&kd)[{NU}], const double (&r)[{NU}]",
+        body, [(f"h{i}", f"h[{i}]") for i in range(NX)],
+        [(f"k{a}", f"kd[{a}]") for a in range(NU)] + [(f"r{a}", f"r[{a}]") for a in range(NU)]))
+
+    # ---- KDXT: acc[a][p] += sum_{j in part p} bcast_j(prod[a]) * one,  a < NU, j < NX, 3 parts
+    #      prod[a] (x lane j) = K[a][j] * dx[j]  =>  sum_p acc[a][p] = (K dx)[a] on every lane
+    NP = 3
+    body = [fmac(f"c{a}_{j % NP}", f"p{a}", "one", j) for j in range(NX) for a in range(NU)]
+    out.append(emit_block(
+        "KDXT", f"double (&acc)[{NU}][{NP}], const double (&prod)[{NU}], const double& one", body,
+        [(f"c{a}_{p}", f"acc[{a}][{p}]") for a in range(NU) for p in range(NP)],
+        [(f"p{a}", f"prod[{a}]") for a in range(NU)] + [("one", "one")]))
 
     # ---- GZ: xn_p += sum_{j in part p} bcast_j(z) * grow[j]   (4 partial sums, j < NZ)
     NP = 4

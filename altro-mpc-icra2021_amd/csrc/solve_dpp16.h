@@ -1,4 +1,5 @@
-// solve_dpp16.h -- whole AL-iLQR solve (Altro.jl `solve!`) as ONE kernel for gfx950.
+// solve_dpp16.h -- whole AL-iLQR solve (Altro.jl `solve!`), and whole MPC steps around it, as
+// ONE kernel for gfx950.
 //
 // Mapping (MI355X-first, see DESIGN.md "Kernel"):
 //   * one 16-lane DPP row  = one MPC instance; one wave64 = 4 instances; one workgroup = 1 wave.
@@ -9,19 +10,42 @@
 //     the broadcast operand comes out of a neighbour lane's register, the other operand and the
 //     accumulator are the lane's own registers.  No LDS traffic and no shuffles in the products;
 //     S, A, B stay in VGPRs for the whole backward pass.
-//   * the serial structure of the solve (AL outer loop / iLQR iterations / line search) runs
-//     inside the kernel with per-instance predicates; branches are wave-uniform (ballot), so
-//     EXEC is all ones wherever a DPP instruction executes.
+//   * HOT LOOPS ARE SINGLE BASIC BLOCKS.  Operands of later knots are requested several knots
+//     ahead and consumed out of registers; hipcc's wait-count insertion can only emit counted
+//     `s_waitcnt vmcnt(N)` for that if the loop body has no branches -- with any (even uniform)
+//     branch in the body it falls back to `vmcnt(0)` at the first use and every knot pays a full
+//     memory round trip (measured: 2.3 k cycles per rollout knot).  So inside the per-knot loops:
+//     indices are clamped instead of guarded, per-knot conditions are selects, stores are
+//     unconditional (into planes that are dead for the rows that do not need them).
+//   * the serial structure of the solve (AL outer loop / iLQR iterations / line search) and of
+//     the MPC loop around it (plant step, shift_fill, retarget, solve) runs inside the kernel with
+//     per-instance predicates; branches are wave-uniform (ballot), so EXEC is all ones wherever
+//     a DPP instruction executes.  Waves never synchronise with each other: instances are
+//     independent, so a wave that draws an easy instance simply moves on.
 //
-// Reference call sites served: solve!(altro) random_linear_problem.jl:113,161;
-// algorithm restated from SURVEY.md Appendix A (rows P2-P9 of SURVEY 8a), the same restatement
-// as oracle/altro_oracle.c, which is the parity oracle for this file.
+// Reference call sites served: solve!(altro) random_linear_problem.jl:113,161; the MPC update
+// sequence :121-139; algorithm restated from SURVEY.md Appendix A (rows P2-P12 of SURVEY 8a),
+// the same restatement as oracle/altro_oracle.c, which is the parity oracle for this file.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
 
 #include "../../include/altro_batch.h"
+
+// tuning knobs (defaults = the shipped configuration; overridable with -D for experiments)
+#ifndef ALTRO_PD_OPEN
+#define ALTRO_PD_OPEN 4      // knots of operand prefetch in the open-loop rollout
+#endif
+#ifndef ALTRO_PD_CLOSED
+#define ALTRO_PD_CLOSED 4    // ... in the closed-loop rollout
+#endif
+#ifndef ALTRO_UN
+#define ALTRO_UN 4           // knots per chunk in the streaming sweeps
+#endif
+#ifndef ALTRO_WAVES_PER_SIMD
+#define ALTRO_WAVES_PER_SIMD 2  // register budget: 512 / this
+#endif
 
 namespace altro {
 
@@ -32,8 +56,10 @@ constexpr int IPW = 4;  // instances per wave
 
 struct SolveParams {
   int B, Bp, N;
-  int kref;              // first knot of the reference window inside Zref
+  int kref;              // first knot of the reference window inside Zref (plain solve)
   int box_k0, box_k1;    // knot range of the BOX constraint (box_k1 < box_k0: none)
+  int first_step;        // MPC mode: first step index
+  int nsteps;            // MPC mode: steps to run in this launch; 0 = plain solve!()
   const double* Gcol;    // [Bp][NX][16]   Gcol[b][k][j] = [A B][k][j]
   const double* Grow;    // [Bp][16][16]   Grow[b][c][i] = [A B][i][c]
   const double* fvec;    // [Bp][16]       affine term (x lanes)
@@ -41,14 +67,15 @@ struct SolveParams {
   const double* wf;      // [16] Qf (x lanes) | 0
   const double* zmin;    // [16]
   const double* zmax;    // [16]
-  const double* x0;      // [Bp][16]
+  double* x0;            // [Bp][16]
   const double* Zref;    // [Nt][Bp][16]
+  const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
   double* Z;             // [2][N][Bp][16]  ping-pong trajectories
   int* cur;              // [Bp] which plane of Z is current
   double* Lhi;           // [N][Bp][16] duals of z - zmax <= 0
   double* Llo;           // [N][Bp][16] duals of zmin - z <= 0
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
-  double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1], then d[a] in lanes >= NX
+  double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
   int* iters;
   int* iters_outer;
   int* status;
@@ -58,6 +85,13 @@ struct SolveParams {
   double* ctrace;        // [Bp][ALTRO_TRACE_LEN]
   long long* n_backward; // [Bp] work counters (accumulated across launches)
   long long* n_rollout;  // [Bp]
+  long long* n_trials;   // [Bp] line-search trials evaluated by interpolation
+  long long* n_solves;   // [Bp]
+  long long* n_iters;    // [Bp]
+  long long* n_ok;       // [Bp] solves that ended SOLVE_SUCCEEDED
+  long long* wave_cycles; // [Bp/4][8] shader cycles of the last launch, per wave (diagnostic):
+                          // total, backward, closed rollouts, open rollouts, todorov, dual update,
+                          // streaming line-search sweeps
   altro_opts o;
 };
 
@@ -95,6 +129,43 @@ __device__ __forceinline__ bool row_any(bool p, int lane) {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// cycle stamp for the per-phase diagnostic counters (one asm statement, fenced both sides).
+// Compiled in only with -DALTRO_PHASE_STAMPS (diagnostic build): the accumulators cost
+// registers in the production kernel.
+#ifdef ALTRO_PHASE_STAMPS
+#define ALTRO_STAMP(x) x
+#else
+#define ALTRO_STAMP(x)
+#endif
+__device__ __forceinline__ long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return (long long)t;
+}
+
+// Global accesses as uniform base (SGPR pair) + 32-bit per-lane BYTE offset: this is the pattern
+// hipcc lowers to `global_load_dwordx2 v, v_off, s[base:base+1]` (one address VGPR instead of a
+// 64-bit pointer per array and unroll slot).  Element index -> byte offset is computed in 32 bits
+// on purpose; the host guarantees every array is smaller than 4 GiB.
+__device__ __forceinline__ double ldg(const double* base, unsigned idx) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+}
+__device__ __forceinline__ void stg(double* base, unsigned idx, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3)) = v;
+}
+
+// 1/x to full FP64 accuracy: v_rcp_f64 + two Newton steps (x > 0, normal range)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+
 // regularization_update! (Altro.jl iLQR) -- same arithmetic as oracle reg_update()
 __device__ __forceinline__ void reg_update(double& rho, double& drho, const altro_opts& o, bool inc) {
   if (inc) {
@@ -114,13 +185,20 @@ struct Solver {
   const SolveParams& P;
   int lane, j, inst;
   bool is_x, is_u;
-  size_t rowoff;   // inst*16 + j
-  size_t kstride;  // Bp*16
+  unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
+  unsigned kstride;  // Bp*16                 that every array stays below 2^32 bytes)
   double wd, wf, zmin, zmax;
   bool has_hi, has_lo;
   double x0;
   double mu;
   int cur;
+  int kref;
+  // results of the last solve
+  int status, iters, iters_outer;
+  double J, cmax;
+  // accumulators over the launch
+  int nbw, nro, nsolve, nit, nok, ntr;
+  ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls;)
 
   __device__ Solver(const SolveParams& p) : P(p) {
     lane = threadIdx.x & 63;
@@ -128,151 +206,378 @@ struct Solver {
     inst = blockIdx.x * IPW + (lane >> 4);
     is_x = j < NX;
     is_u = (j >= NX) && (j < NZ);
-    rowoff = (size_t)inst * LW + j;
-    kstride = (size_t)P.Bp * LW;
+    rowoff = (unsigned)inst * LW + j;
+    kstride = (unsigned)P.Bp * LW;
     wd = P.wd[j];
     wf = P.wf[j];
     zmin = P.zmin[j];
     zmax = P.zmax[j];
     has_hi = zmax < 1e300;
     has_lo = zmin > -1e300;
-    x0 = P.x0[rowoff];
+    x0 = ldg(P.x0, rowoff);
     cur = P.cur[inst];
+    mu = P.mu[inst];
+    kref = P.kref;
+    status = ALTRO_UNSOLVED;
+    iters = iters_outer = 0;
+    J = cmax = 0.0;
+    nbw = nro = nsolve = nit = nok = ntr = 0;
+    ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
   }
 
-  __device__ __forceinline__ size_t at(int k) const { return (size_t)k * kstride + rowoff; }
-  __device__ __forceinline__ double* plane(int c) const { return P.Z + (size_t)c * P.N * kstride; }
+  __device__ __forceinline__ unsigned at(int k) const { return (unsigned)k * kstride + rowoff; }
+  // plane c of Z as an element offset (per instance: cur differs between rows)
+  __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * kstride; }
   __device__ __forceinline__ bool box_at(int k) const { return k >= P.box_k0 && k <= P.box_k1; }
+  __device__ __forceinline__ unsigned kd_at(int k, int row) const {
+    return (((unsigned)k * P.Bp + inst) * NU + row) * LW + j;
+  }
+  static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+  static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+  // max over the NU control lanes of this row
+  __device__ __forceinline__ double umax(double v) const {
+    double m = bcast<NX>(v);
+    sfor<1, NU>([&](auto a) { m = fmax(m, bcast<NX + decltype(a)::value>(v)); });
+    return m;
+  }
 
   // stage cost + box AL term of this lane's element; updates the lane's violation maximum.
-  // (oracle total_cost / con_cost; TO.jl cost!  -- SURVEY A.2)
+  // Branch-free: box_on only selects.  (oracle total_cost / con_cost; TO.jl cost! -- SURVEY A.2)
   __device__ __forceinline__ double lane_cost(double z, double zr, double w, double lhi, double llo,
                                               bool box_on, double& viol) const {
-    double e = z - zr;
-    double J = 0.5 * w * e * e;
-    if (box_on) {
-      double chi = z - zmax, clo = zmin - z;
-      bool ahi = (chi >= 0.0) || (lhi > 0.0);
-      bool alo = (clo >= 0.0) || (llo > 0.0);
-      double Jhi = lhi * chi + (ahi ? 0.5 * mu * chi * chi : 0.0);
-      double Jlo = llo * clo + (alo ? 0.5 * mu * clo * clo : 0.0);
-      J += has_hi ? Jhi : 0.0;
-      J += has_lo ? Jlo : 0.0;
-      viol = fmax(viol, has_hi ? chi : 0.0);
-      viol = fmax(viol, has_lo ? clo : 0.0);
-    }
-    return J;
+    const double e = z - zr;
+    double Jl = 0.5 * w * e * e;
+    const double chi = z - zmax, clo = zmin - z;
+    const bool ahi = (chi >= 0.0) || (lhi > 0.0);
+    const bool alo = (clo >= 0.0) || (llo > 0.0);
+    const double Jhi = lhi * chi + (ahi ? 0.5 * mu * chi * chi : 0.0);
+    const double Jlo = llo * clo + (alo ? 0.5 * mu * clo * clo : 0.0);
+    const bool bh = box_on && has_hi, bl = box_on && has_lo;
+    Jl += bh ? Jhi : 0.0;
+    Jl += bl ? Jlo : 0.0;
+    viol = fmax(viol, bh ? chi : 0.0);
+    viol = fmax(viol, bl ? clo : 0.0);
+    return Jl;
   }
 
   struct RollOut {
-    double J, cmax, grad_new, grad_old;
+    double J, cmax;
     bool limit;
+    bool unchanged;  // the trial reproduced plane `cur` bit for bit (closed-loop rollouts only)
   };
 
-  // rollout!(solver[, alpha]) fused with cost!(obj, Z̄), max_violation and gradient_todorov!.
-  //   OPEN : open-loop rollout of plane `cur` from x0 (iLQR initialize!), in place
-  //   !OPEN: closed-loop rollout with gains KD and step alpha from plane cur into plane cur^1;
-  //          stores are predicated on `store` (per instance)
-  template <bool OPEN>
+  struct KnotIn {
+    double z, zr, lhi, llo;
+    double kcol[NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] in kcol[a]
+  };
+
+  // rollout!(solver[, alpha]) fused with cost!(obj, Z̄) and max_violation.
+  //   OPEN : open-loop rollout of plane `cur` from x0 (iLQR initialize!), in place.  With SHIFT
+  //          the controls and box duals are read one knot ahead and written back in place:
+  //          RD.shift_fill!(Z) + Altro.shift_fill!(conSet) folded into the same sweep
+  //          (random_linear_problem.jl:136,139).
+  //   !OPEN: closed-loop rollout with gains KD and step alpha from plane cur into plane cur^1
+  //          (dead storage for every row that is not line-searching, so stores need no mask).
+  //   PRED : stores masked by `store` (open rollouts of waves that hold a finished instance,
+  //          whose plane must stay bit-identical); the fast variants store unconditionally.
+  template <bool OPEN, bool SHIFT, bool PRED>
   __device__ RollOut rollout(double alpha, bool store) {
-    const double* zs = plane(cur);
-    double* zd = OPEN ? plane(cur) : plane(cur ^ 1);
+    const unsigned zs = plane(cur);
+    const unsigned zd = OPEN ? plane(cur) : plane(cur ^ 1);
+    const int N = P.N;
     double grow[NZ];
     sfor<0, NZ>([&](auto c) {
       constexpr int C = decltype(c)::value;
-      grow[C] = P.Grow[((size_t)inst * LW + C) * LW + j];
+      grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
     });
-    const double fv = P.fvec[rowoff];
+    const double fv = ldg(P.fvec, rowoff);
     double xb = x0;
-    double Jacc = 0.0, viol = 0.0, gnew = 0.0, gold = 0.0;
-    bool limit = false;
-    const int N = P.N;
-    for (int k = 0; k < N - 1; ++k) {
-      const double z = zs[at(k)];
-      const double zr = P.Zref[at(P.kref + k)];
-      const bool bx = box_at(k);
-      double lhi = 0.0, llo = 0.0;
-      if (bx) {
-        lhi = P.Lhi[at(k)];
-        llo = P.Llo[at(k)];
+    double Jacc = 0.0, viol = 0.0;
+    bool limit = false, changed = false;
+    const int k1 = P.box_k1;
+
+    // operands of stage knot k (k clamped to 0..N-2 by the callers)
+    auto load = [&](int k, KnotIn& in) {
+      const int ku = SHIFT ? imin(k + 1, N - 2) : k;            // controls one knot ahead
+      const int kl = SHIFT ? imax(imin(k + 1, k1), 0) : k;       // duals one knot ahead
+      in.z = ldg(P.Z, zs + at((SHIFT && !is_x) ? ku : k));
+      in.zr = ldg(P.Zref, at(kref + k));
+      in.lhi = ldg(P.Lhi, at(kl));
+      in.llo = ldg(P.Llo, at(kl));
+      if constexpr (!OPEN) {
+        sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
       }
+    };
+
+    auto stage = [&](int k, const KnotIn& in) {
+      const bool bx = box_at(k);
+      const double lhi = bx ? in.lhi : 0.0, llo = bx ? in.llo : 0.0;
       double zb;
       if constexpr (OPEN) {
-        zb = is_x ? xb : z;
+        zb = is_x ? xb : in.z;
+        if constexpr (PRED) {
+          if (store) stg(P.Z, zd + at(k), zb);
+        } else {
+          stg(P.Z, zd + at(k), zb);
+        }
+        if constexpr (SHIFT) {
+          stg(P.Lhi, at(k), lhi);
+          stg(P.Llo, at(k), llo);
+        }
       } else {
-        // u-lane NX+a reads row a of the gain block: K[a][0..NX-1] and d[a] (stored in lanes >= NX)
-        double krow[NX];
-        double dff = 0.0;
-        const int ra = is_u ? (j - NX) : 0;
-        const double* kd = P.KD + (((size_t)k * P.Bp + inst) * NU + ra) * LW;
-        sfor<0, NX>([&](auto c) { krow[decltype(c)::value] = kd[decltype(c)::value]; });
-        dff = kd[NX];
-        double dx = is_x ? (xb - z) : 0.0;
-        double acc[3] = {0.0, 0.0, 0.0};
-        Blk<NX, NU>::KDX(acc, dx, krow);
-        double du = (acc[0] + acc[1]) + acc[2];
-        double ub = z + du + alpha * dff;
+        // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
+        const double dx = is_x ? (xb - in.z) : 0.0;
+        double prod[NU], acc[NU][3];
+        sfor<0, NU>([&](auto a) {
+          constexpr int A = decltype(a)::value;
+          prod[A] = is_x ? in.kcol[A] * dx : 0.0;
+          acc[A][0] = acc[A][1] = acc[A][2] = 0.0;
+        });
+        const double one = 1.0;
+        Blk<NX, NU>::KDXT(acc, prod, one);
+        double du = (acc[0][0] + acc[0][1]) + acc[0][2];
+        double dff = in.kcol[0];
+        sfor<1, NU>([&](auto a) {
+          constexpr int A = decltype(a)::value;
+          const double da = (acc[A][0] + acc[A][1]) + acc[A][2];
+          du = (j == NX + A) ? da : du;
+          dff = (j == NX + A) ? in.kcol[A] : dff;
+        });
+        const double ub = in.z + du + alpha * dff;
         zb = is_x ? xb : ub;
-        double gn = is_u ? fabs(dff) / (fabs(ub) + 1.0) : 0.0;
-        double go = is_u ? fabs(dff) / (fabs(z) + 1.0) : 0.0;
-        gnew += row_max(gn);
-        gold += row_max(go);
-        if (store) zd[at(k)] = zb;
+        changed = changed || ((is_x || is_u) && (zb != in.z));
+        stg(P.Z, zd + at(k), zb);
       }
-      if constexpr (OPEN) {
-        if (store) zd[at(k)] = zb;
-      }
-      Jacc += lane_cost(zb, zr, wd, lhi, llo, bx, viol);
+      Jacc += lane_cost(zb, in.zr, wd, lhi, llo, bx, viol);
       const double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
       limit = limit || ((is_x || is_u) && !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
       Blk<NX, NU>::GZ(acc4, zb, grow);
       xb = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    };
+
+    // terminal-knot operands (independent of the pipeline)
+    const int kt = N - 1;
+    const double t_zr = ldg(P.Zref, at(kref + kt));
+    const double t_lhi = ldg(P.Lhi, at(kt)), t_llo = ldg(P.Llo, at(kt));
+    double t_z = 0.0;
+    if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
+
+    // software pipeline: operands of knot k+PD are requested right after knot k is consumed.
+    // The main loop body is one basic block (PD stages, PD clamped loads).
+    constexpr int PD = OPEN ? ALTRO_PD_OPEN : ALTRO_PD_CLOSED;
+    KnotIn ring[PD];
+    sfor<0, PD>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      load(imin(U, N - 2), ring[U]);
+    });
+    const int ngroups = (N - 1) / PD;
+    int k = 0;
+    for (int g = 0; g < ngroups; ++g, k += PD) {
+      sfor<0, PD>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        stage(k + U, ring[U]);
+        load(imin(k + U + PD, N - 2), ring[U]);
+      });
+    }
+    {  // remaining (N-1) % PD stage knots
+      const int rem = (N - 1) - k;
+      sfor<0, PD>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        if (U < rem) stage(k + U, ring[U]);
+      });
     }
     {  // terminal knot: state only
-      const int k = N - 1;
-      const double zr = P.Zref[at(P.kref + k)];
-      const bool bx = box_at(k);
-      double lhi = 0.0, llo = 0.0;
-      if (bx) {
-        lhi = P.Lhi[at(k)];
-        llo = P.Llo[at(k)];
+      const bool bx = box_at(kt);
+      const double zb = is_x ? xb : 0.0;
+      if constexpr (PRED) {
+        if (store) stg(P.Z, zd + at(kt), zb);
+      } else {
+        stg(P.Z, zd + at(kt), zb);
       }
-      double zb = is_x ? xb : 0.0;
-      if (store) zd[at(k)] = zb;
-      Jacc += lane_cost(zb, zr, wf, lhi, llo, bx && is_x, viol);
+      Jacc += lane_cost(zb, t_zr, wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx && is_x, viol);
       limit = limit || (is_x && !(fabs(zb) <= P.o.max_state_value));
+      if constexpr (!OPEN) changed = changed || (is_x && (zb != t_z));
     }
     RollOut r;
     r.J = row_sum(Jacc);
     r.cmax = row_max(viol);
-    r.grad_new = gnew / (double)(N - 1);
-    r.grad_old = gold / (double)(N - 1);
     r.limit = row_any(limit, lane);
+    r.unchanged = !row_any(changed, lane);
     return r;
+  }
+
+  // gradient_todorov!: mean_k max_a |d_k,a| / (|u_k,a| + 1) on the current plane.  Evaluated
+  // lazily: the reference only uses it in the convergence test, which also needs dJ < tol.
+  __device__ double todorov() {
+    const unsigned zs = plane(cur);
+    const int N = P.N;
+    const int ra = is_u ? (j - NX) : 0;
+    double acc = 0.0;
+    constexpr int UN = ALTRO_UN;
+    const int nch = (N - 1 + UN - 1) / UN;
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * UN;
+      double u[UN], d[UN];
+      sfor<0, UN>([&](auto t) {
+        constexpr int Tt = decltype(t)::value;
+        const int k = imin(k0 + Tt, N - 2);
+        u[Tt] = ldg(P.Z, zs + at(k));
+        d[Tt] = ldg(P.KD, kd_at(k, ra));
+      });
+      sfor<0, UN>([&](auto t) {
+        constexpr int Tt = decltype(t)::value;
+        const double v = fabs(d[Tt]) / (fabs(u[Tt]) + 1.0);
+        const double m = umax(v);
+        acc += (k0 + Tt < N - 1) ? m : 0.0;
+      });
+    }
+    return acc / (double)(N - 1);
+  }
+
+  // ---- line search on alpha < 1 without new rollouts ------------------------------------
+  // Dynamics are linear/affine and the control law u + K dx + alpha d is affine, so the trial
+  // trajectory is affine in alpha:  Z̄(alpha) = Z + alpha (Z̄(1) - Z)  (exact identity; alpha is a
+  // power of two, so alpha*(Z̄(1)-Z) is exact in FP64 and the only rounding is the final add).
+  // Plane cur^1 holds Z̄(1) from the alpha = 1 rollout.  trial_costs evaluates cost!, the
+  // violation, the state/control limits and the "reproduces Z bit for bit" test for NA
+  // consecutive step sizes alpha, alpha/2, ... in ONE streaming sweep (no gains, no serial chain).
+  static constexpr int NA = 4;
+  struct Trials {
+    double J[NA], cmax[NA];
+    bool limit[NA], unchanged[NA];
+  };
+
+  __device__ void trial_costs(double alpha, Trials& T) {
+    const unsigned zs = plane(cur);
+    const unsigned z1 = plane(cur ^ 1);
+    const int N = P.N;
+    double Jacc[NA], viol[NA];
+    bool lim[NA], chg[NA];
+    double a[NA];
+    sfor<0, NA>([&](auto t) {
+      constexpr int Tt = decltype(t)::value;
+      Jacc[Tt] = 0.0;
+      viol[Tt] = 0.0;
+      lim[Tt] = false;
+      chg[Tt] = false;
+      a[Tt] = alpha * (1.0 / (double)(1 << Tt));
+    });
+    const bool live = is_x || is_u;
+    const double lm = is_x ? P.o.max_state_value : P.o.max_control_value;
+    constexpr int UN = ALTRO_UN;
+    const int nch = (N + UN - 1) / UN;
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * UN;
+      double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN];
+      sfor<0, UN>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        const int k = imin(k0 + Q, N - 1);
+        z[Q] = ldg(P.Z, zs + at(k));
+        zz1[Q] = ldg(P.Z, z1 + at(k));
+        zr[Q] = ldg(P.Zref, at(kref + k));
+        lhi[Q] = ldg(P.Lhi, at(k));
+        llo[Q] = ldg(P.Llo, at(k));
+      });
+      sfor<0, UN>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        const int k = k0 + Q;
+        const bool valid = k < N;
+        const bool term = (k >= N - 1);
+        const bool bx = box_at(k) && valid;
+        const double dz = zz1[Q] - z[Q];
+        const double w = valid ? (term ? wf : wd) : 0.0;
+        const bool on = (term ? is_x : live) && valid;
+        const double lh = bx ? lhi[Q] : 0.0, ll = bx ? llo[Q] : 0.0;
+        sfor<0, NA>([&](auto t) {
+          constexpr int Tt = decltype(t)::value;
+          const double zb = on ? __builtin_fma(a[Tt], dz, z[Q]) : 0.0;
+          Jacc[Tt] += lane_cost(zb, on ? zr[Q] : 0.0, w, lh, ll, bx && on, viol[Tt]);
+          lim[Tt] = lim[Tt] || (on && !(fabs(zb) <= lm));
+          chg[Tt] = chg[Tt] || (on && (zb != z[Q]));
+        });
+      });
+    }
+    sfor<0, NA>([&](auto t) {
+      constexpr int Tt = decltype(t)::value;
+      T.J[Tt] = row_sum(Jacc[Tt]);
+      T.cmax[Tt] = row_max(viol[Tt]);
+      T.limit[Tt] = row_any(lim[Tt], lane);
+      T.unchanged[Tt] = !row_any(chg[Tt], lane);
+    });
+  }
+
+  // Z̄ <- Z + alpha (Z̄(1) - Z) in plane cur^1, for the instances flagged `doit`
+  __device__ void interpolate(double alpha, bool doit) {
+    const unsigned zs = plane(cur);
+    const unsigned z1 = plane(cur ^ 1);
+    const int N = P.N;
+    constexpr int UN = ALTRO_UN;
+    const int nch = (N + UN - 1) / UN;
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * UN;
+      double z[UN], zz1[UN];
+      sfor<0, UN>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        const int k = imin(k0 + Q, N - 1);
+        z[Q] = ldg(P.Z, zs + at(k));
+        zz1[Q] = ldg(P.Z, z1 + at(k));
+      });
+      sfor<0, UN>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        const int k = k0 + Q;
+        const bool on = (k >= N - 1) ? is_x : (is_x || is_u);
+        const double zb = on ? __builtin_fma(alpha, zz1[Q] - z[Q], z[Q]) : 0.0;
+        if (doit && k < N) stg(P.Z, z1 + at(k), zb);
+      });
+    }
+  }
+
+  // gradient / Gauss-Newton hessian of the box AL term of this lane's element (branch-free)
+  __device__ __forceinline__ void box_expand(double z, double lhi, double llo, bool on, double& qz,
+                                             double& hz) const {
+    const double chi = z - zmax, clo = zmin - z;
+    const bool ahi = (chi >= 0.0) || (lhi > 0.0);
+    const bool alo = (clo >= 0.0) || (llo > 0.0);
+    const double ghi = lhi + (ahi ? mu * chi : 0.0);
+    const double glo = llo + (alo ? mu * clo : 0.0);
+    const bool bh = on && has_hi, bl = on && has_lo;
+    qz += bh ? ghi : 0.0;
+    hz += (bh && ahi) ? mu : 0.0;
+    qz -= bl ? glo : 0.0;
+    hz += (bl && alo) ? mu : 0.0;
   }
 
   // backwardpass! (SURVEY A.3 / oracle backward_pass): Riccati recursion over plane `cur`,
   // writes the gain blocks KD, returns dV and whether any Quu pivot was not positive.
+  //
+  // Algebra used (exact identities of the reference's formulas, with Quu_reg = Quu + rho I and
+  // Quu_reg K = -Qux, Quu_reg d = -Qu):
+  //     Quu K + Qux = -rho K,  Quu d + Qu = -rho d
+  //     S = Qxx + K'(Quu K + Qux) + Qux'K = Qxx + Qux'K - rho K'K
+  //     s = Qx + K'(Quu d + Qu) + Qux'd  = Qx + Qux'd - rho K'd
+  //     dV = (d'Qu, 1/2 d'Quu d)         = (d'Qu, -1/2 d'Qu - 1/2 rho d'd)
+  // Quu_reg is factored as L D L' (no square roots; pivots D_j > 0 is the same PD test as
+  // Cholesky's).  RHO = false is the rho == 0 instantiation (every convex run).
+  template <bool RHO>
   __device__ void backward(double rho, double& dV1, double& dV2, bool& fail, double* sm) {
-    const double* zs = plane(cur);
+    const unsigned zs = plane(cur);
     double g[NX];
     sfor<0, NX>([&](auto c) {
       constexpr int C = decltype(c)::value;
-      g[C] = P.Gcol[((size_t)inst * NX + C) * LW + j];
+      g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
     });
     const int N = P.N;
     // terminal expansion: S = Qf (+ box hessian), s = Qf (x - xr) (+ box gradient)
     double Sx[NX + 1];
     {
       const int k = N - 1;
-      const double z = zs[at(k)];
-      const double zr = P.Zref[at(P.kref + k)];
+      const double z = ldg(P.Z, zs + at(k));
+      const double zr = ldg(P.Zref, at(kref + k));
+      const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
       double qz = wf * (z - zr), hz = wf;
-      if (box_at(k)) {
-        const double lhi = P.Lhi[at(k)], llo = P.Llo[at(k)];
-        box_expand(z, lhi, llo, is_x, qz, hz);
-      }
+      box_expand(z, lhi, llo, box_at(k) && is_x, qz, hz);
       sfor<0, NX>([&](auto c) {
         constexpr int C = decltype(c)::value;
         Sx[C] = (j == C) ? hz : 0.0;
@@ -282,14 +587,17 @@ struct Solver {
     dV1 = 0.0;
     dV2 = 0.0;
     fail = false;
-    for (int k = N - 2; k >= 0; --k) {
-      const double z = zs[at(k)];
-      const double zr = P.Zref[at(P.kref + k)];
+    double* my = sm + (lane >> 4) * (LW * (LW + 1));
+    // operands of the knot about to be processed (loaded one knot ahead)
+    double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
+    double lhi = ldg(P.Lhi, at(N - 2)), llo = ldg(P.Llo, at(N - 2));
+    for (int k = N - 2; k >= 0; --k) {   // body: one basic block
+      const int km = imax(k - 1, 0);
+      const double zn = ldg(P.Z, zs + at(km));
+      const double zrn = ldg(P.Zref, at(kref + km));
+      const double lhin = ldg(P.Lhi, at(km)), llon = ldg(P.Llo, at(km));
       double qz = wd * (z - zr), hz = wd;
-      if (box_at(k)) {
-        const double lhi = P.Lhi[at(k)], llo = P.Llo[at(k)];
-        box_expand(z, lhi, llo, true, qz, hz);
-      }
+      box_expand(z, lhi, llo, box_at(k), qz, hz);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
       double w[NX + 1];
       sfor<0, NX + 1>([&](auto c) { w[decltype(c)::value] = 0.0; });
@@ -311,25 +619,28 @@ struct Solver {
         sfor<0, A + 1>([&](auto b) {
           constexpr int Bq = decltype(b)::value;
           quu[A][Bq] = bcast<NX + Bq>(h[NX + A]);
-          quu[Bq][A] = quu[A][Bq];
         });
       });
-      // Cholesky of Quu + rho I (redundantly on every lane)
-      double L[NU][NU];
-      double inv[NU];
+      // L D L' of Quu + rho I (redundantly on every lane); Ld[i][k] = L[i][k]*D[k]
+      double L[NU][NU], Ld[NU][NU], dinv[NU];
       sfor<0, NU>([&](auto jc) {
         constexpr int Jc = decltype(jc)::value;
-        double dd = quu[Jc][Jc] + rho;
-        sfor<0, Jc>([&](auto kk) { dd -= L[Jc][decltype(kk)::value] * L[Jc][decltype(kk)::value]; });
+        double dd = RHO ? quu[Jc][Jc] + rho : quu[Jc][Jc];
+        sfor<0, Jc>([&](auto kk) {
+          constexpr int Kk = decltype(kk)::value;
+          dd -= L[Jc][Kk] * Ld[Jc][Kk];
+        });
         fail = fail || !(dd > 0.0);
-        const double sq = sqrt(dd);
-        L[Jc][Jc] = sq;
-        inv[Jc] = 1.0 / sq;
+        dinv[Jc] = rcp_nr(dd);
         sfor<Jc + 1, NU>([&](auto ii) {
           constexpr int I = decltype(ii)::value;
           double v = quu[I][Jc];
-          sfor<0, Jc>([&](auto kk) { v -= L[I][decltype(kk)::value] * L[Jc][decltype(kk)::value]; });
-          L[I][Jc] = v * inv[Jc];
+          sfor<0, Jc>([&](auto kk) {
+            constexpr int Kk = decltype(kk)::value;
+            v -= L[I][Kk] * Ld[Jc][Kk];
+          });
+          Ld[I][Jc] = v;
+          L[I][Jc] = v * dinv[Jc];
         });
       });
       // right-hand side: x lanes Qux(:,j), u lanes Qu  -> kd = -Quu_reg^{-1} rhs
@@ -344,118 +655,103 @@ struct Solver {
           constexpr int I = decltype(ii)::value;
           double v = r[I];
           sfor<0, I>([&](auto kk) { v -= L[I][decltype(kk)::value] * y[decltype(kk)::value]; });
-          y[I] = v * inv[I];
+          y[I] = v;
         });
         sfor<0, NU>([&](auto ir) {
           constexpr int I = NU - 1 - decltype(ir)::value;
-          double v = y[I];
+          double v = y[I] * dinv[I];
           sfor<I + 1, NU>([&](auto kk) { v -= L[decltype(kk)::value][I] * kd[decltype(kk)::value]; });
-          kd[I] = v * inv[I];
+          kd[I] = v;
         });
         sfor<0, NU>([&](auto a) { kd[decltype(a)::value] = -kd[decltype(a)::value]; });
       }
-      // T = Quu*kd + rhs : x lanes (Quu K + Qux)(:,j), u lanes Quu d + Qu
-      double T[NU];
+      // d to every lane (from the first u lane)
+      double dd_[NU];
+      sfor<0, NU>([&](auto a) { dd_[decltype(a)::value] = bcast<NX>(kd[decltype(a)::value]); });
+      // s = Qx + Qux'd - rho K'd ;  dV += (d'Qu, -1/2 d'Qu - 1/2 rho d'd)
+      double snew = gz, t1 = 0.0, dtd = 0.0, ktd = 0.0;
       sfor<0, NU>([&](auto a) {
         constexpr int A = decltype(a)::value;
-        double v = r[A];
-        sfor<0, NU>([&](auto b) { v += quu[A][decltype(b)::value] * kd[decltype(b)::value]; });
-        T[A] = v;
-      });
-      // d and (Quu d + Qu) to every lane (from the first u lane)
-      double dd_[NU], Td[NU];
-      sfor<0, NU>([&](auto a) {
-        constexpr int A = decltype(a)::value;
-        dd_[A] = bcast<NX>(kd[A]);
-        Td[A] = bcast<NX>(T[A]);
-      });
-      // s = Qx + K'(Quu d + Qu) + Qux' d
-      double snew = gz;
-      sfor<0, NU>([&](auto a) {
-        constexpr int A = decltype(a)::value;
-        snew += kd[A] * Td[A] + r[A] * dd_[A];
-      });
-      // dV += (d'Qu, 1/2 d'Quu d)
-      double t1 = 0.0, t2 = 0.0;
-      sfor<0, NU>([&](auto a) {
-        constexpr int A = decltype(a)::value;
+        snew += r[A] * dd_[A];
         t1 += dd_[A] * qu[A];
-        t2 += 0.5 * dd_[A] * (Td[A] - qu[A]);
+        if constexpr (RHO) {
+          dtd += dd_[A] * dd_[A];
+          ktd += kd[A] * dd_[A];
+        }
       });
+      if constexpr (RHO) snew -= rho * ktd;
       dV1 += t1;
-      dV2 += t2;
-      // gains out: row a lanes 0..NX-1 = K[a][:], lanes >= NX = d[a]
-      {
-        double* kdp = P.KD + (((size_t)k * P.Bp + inst) * NU) * LW + j;
-        sfor<0, NU>([&](auto a) {
-          constexpr int A = decltype(a)::value;
-          kdp[A * LW] = is_x ? kd[A] : dd_[A];
-        });
+      dV2 += RHO ? (-0.5 * t1 - 0.5 * rho * dtd) : (-0.5 * t1);
+      // gains out, every lane stores its own column: x lanes K[a][j], lanes >= NX d[a]
+      sfor<0, NU>([&](auto a) {
+        constexpr int A = decltype(a)::value;
+        stg(P.KD, kd_at(k, A), is_x ? kd[A] : dd_[A]);
+      });
+      // S = Qxx + Qux'K - rho K'K   (in place on h[0..NX-1]), then S = (S + S')/2
+      if constexpr (RHO) {
+        double T[NU];
+        sfor<0, NU>([&](auto a) { T[decltype(a)::value] = -rho * kd[decltype(a)::value]; });
+        Blk<NX, NU>::CTG(h, kd, T, r);
+      } else {
+        Blk<NX, NU>::CTG0(h, kd, r);
       }
-      // S = Qxx + K'(Quu K + Qux) + Qux'K   (in place on h[0..NX-1]), then S = (S + S')/2
-      Blk<NX, NU>::CTG(h, kd, T, r);
-      {
-        double* my = sm + (size_t)(lane >> 4) * (LW * (LW + 1));
-        sfor<0, NX>([&](auto c) {
-          constexpr int C = decltype(c)::value;
-          my[C * (LW + 1) + j] = h[C];
-        });
-        __syncthreads();
-        sfor<0, NX>([&](auto c) {
-          constexpr int C = decltype(c)::value;
-          const double st = my[j * (LW + 1) + C];
-          Sx[C] = is_x ? 0.5 * (h[C] + st) : 0.0;
-        });
-        __syncthreads();
-      }
-      Sx[NX] = is_x ? snew : 0.0;
-    }
-  }
-
-  // gradient / Gauss-Newton hessian of the box AL term of this lane's element
-  __device__ __forceinline__ void box_expand(double z, double lhi, double llo, bool on, double& qz,
-                                             double& hz) const {
-    const double chi = z - zmax, clo = zmin - z;
-    const bool ahi = (chi >= 0.0) || (lhi > 0.0);
-    const bool alo = (clo >= 0.0) || (llo > 0.0);
-    const double ghi = lhi + (ahi ? mu * chi : 0.0);
-    const double glo = llo + (alo ? mu * clo : 0.0);
-    if (on && has_hi) {
-      qz += ghi;
-      hz += ahi ? mu : 0.0;
-    }
-    if (on && has_lo) {
-      qz -= glo;
-      hz += alo ? mu : 0.0;
+      // transpose through LDS.  The workgroup is ONE wave and each instance has its own LDS
+      // region, so no s_barrier is needed: LDS operations of a wave execute in issue order.
+      // Lanes >= NX read rows that were never written and carry garbage columns from here on;
+      // nothing ever reads a column of a lane >= NX (the DPP broadcasts only source lanes < NX).
+      sfor<0, NX>([&](auto c) {
+        constexpr int C = decltype(c)::value;
+        my[C * (LW + 1) + j] = h[C];
+      });
+      __builtin_amdgcn_wave_barrier();
+      sfor<0, NX>([&](auto c) {
+        constexpr int C = decltype(c)::value;
+        const double st = my[j * (LW + 1) + C];
+        Sx[C] = 0.5 * (h[C] + st);
+      });
+      __builtin_amdgcn_wave_barrier();
+      Sx[NX] = snew;
+      z = zn;
+      zr = zrn;
+      lhi = lhin;
+      llo = llon;
     }
   }
 
   // dual_update! for the box rows of plane `cur` (penalty_update! is the caller's mu *= phi)
   __device__ void dual_update(bool upd) {
-    const double* zs = plane(cur);
+    const unsigned zs = plane(cur);
     const double dmax = P.o.dual_max;
     for (int k = P.box_k0; k <= P.box_k1; ++k) {
       const bool on = (k < P.N - 1) ? (is_x || is_u) : is_x;
-      const double z = zs[at(k)];
-      const double lhi = P.Lhi[at(k)], llo = P.Llo[at(k)];
+      const double z = ldg(P.Z, zs + at(k));
+      const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
       const double nhi = fmin(fmax(lhi + mu * (z - zmax), 0.0), dmax);
       const double nlo = fmin(fmax(llo + mu * (zmin - z), 0.0), dmax);
-      if (upd && on && has_hi) P.Lhi[at(k)] = nhi;
-      if (upd && on && has_lo) P.Llo[at(k)] = nlo;
+      if (upd && on && has_hi) stg(P.Lhi, at(k), nhi);
+      if (upd && on && has_lo) stg(P.Llo, at(k), nlo);
     }
   }
 
-  // solve!(::ALTROSolver) -> AL outer loop -> iLQR (oracle orc_solve)
-  __device__ void solve(double* sm) {
+  // solve!(::ALTROSolver) -> AL outer loop -> iLQR (oracle orc_solve).
+  // `shift`: fold shift_fill! of controls and duals into the first open-loop rollout.
+  __device__ void solve(double* sm, bool shift) {
     const altro_opts& o = P.o;
     const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
     const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
-    mu = o.reset_penalties ? mu0 : P.mu[inst];
-    int status = ALTRO_UNSOLVED;
-    int iters = 0, iters_outer = 0;
-    int nbw = 0, nro = 0;  // work counters of this instance
+    if (o.reset_penalties) mu = mu0;
+    if (o.reset_duals) {  // initialize!: lambda <- 0
+      for (int k = P.box_k0; k <= P.box_k1; ++k) {
+        stg(P.Lhi, at(k), 0.0);
+        stg(P.Llo, at(k), 0.0);
+      }
+    }
+    status = ALTRO_UNSOLVED;
+    iters = 0;
+    iters_outer = 0;
     bool alive = true;
-    double J = 0.0, cmax = 0.0;
+    J = 0.0;
+    cmax = 0.0;
     const bool has_con = P.box_k1 >= P.box_k0;
     const int n_outer = has_con ? o.iterations_outer : 1;
 
@@ -468,7 +764,17 @@ struct Solver {
       double rho = o.bp_reg_initial, drho = 0.0;
       int dj_zero = 0;
       bool inner = alive;
-      RollOut r0 = rollout<true>(0.0, inner);
+      ALTRO_STAMP(long long ts = stamp();)
+      // every row alive: in-place open rollout with unconditional stores; a finished row's plane
+      // must stay bit-identical, so waves that hold one take the predicated variant
+      RollOut r0;
+      if (!wave_any(!alive)) {
+        if (shift && outer == 0) r0 = rollout<true, true, false>(0.0, true);
+        else r0 = rollout<true, false, false>(0.0, true);
+      } else {
+        r0 = rollout<true, false, true>(0.0, inner);
+      }
+      ALTRO_STAMP(t_ro += stamp() - ts;)
       if (inner) nro++;
       double J_prev = r0.J;
       if (inner) {
@@ -487,7 +793,10 @@ struct Solver {
         // backward pass (with regularisation restarts)
         while (true) {
           bool fail;
-          backward(rho, dV1, dV2, fail, sm);
+          ALTRO_STAMP(ts = stamp();)
+          if (wave_any(rho != 0.0)) backward<true>(rho, dV1, dV2, fail, sm);
+          else backward<false>(rho, dV1, dV2, fail, sm);
+          ALTRO_STAMP(t_bw += stamp() - ts;)
           if (inner) nbw++;
           fail = row_any(fail, lane) && inner;
           if (fail) {
@@ -503,10 +812,46 @@ struct Solver {
             break;
           }
         }
-        // forward pass: line search on alpha
-        double alpha = 1.0, zr = -1.0, Jn = __builtin_inf(), cm_n = cmax, g_n = 0.0;
+        // forward pass: line search on alpha (forwardpass!).  Trial 0 (alpha = 1) is
+        // the closed-loop rollout; later trials are evaluated by interpolation, NA per sweep.
+        double alpha = 1.0, zr = -1.0, Jn = __builtin_inf(), cm_n = cmax;
         int ls = 0;
-        bool searching = inner, accepted = false;
+        bool searching = inner, accepted = false, need_interp = false;
+        // one trial of the reference loop body for an instance that is still searching
+        auto trial = [&](double a_t, double J_t, double cm_t, bool lim_t, bool unch_t) {
+          if (lim_t) {
+            ls++;
+            alpha = 0.5 * a_t;
+            return;
+          }
+          Jn = J_t;
+          const double expected = -a_t * (dV1 + a_t * dV2);
+          zr = (expected > 0.0) ? (J_prev - Jn) / expected : -1.0;
+          ls++;
+          const bool again = ((zr <= o.line_search_lower_bound) || (zr > o.line_search_upper_bound)) &&
+                             (Jn >= J_prev);
+          if (!again) {
+            searching = false;
+            accepted = true;
+            cm_n = cm_t;
+            alpha = a_t;
+          } else {
+            alpha = 0.5 * a_t;
+            // Exact early-out: if this trial reproduced the current trajectory bit for bit, every
+            // smaller alpha reproduces it too (round-to-nearest is monotone), J stays == J_prev,
+            // and the reference loop would spin to iterations_linesearch and fail.  Jump there.
+            if (unch_t) ls = o.iterations_linesearch + 1;
+          }
+        };
+        {
+          ALTRO_STAMP(ts = stamp();)
+          RollOut rr = rollout<false, false, false>(1.0, true);
+          ALTRO_STAMP(t_rc += stamp() - ts;)
+          if (searching) {
+            nro++;
+            trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged);
+          }
+        }
         while (true) {
           const bool failnow = searching && (ls > o.iterations_linesearch);
           if (failnow) {
@@ -518,31 +863,27 @@ struct Solver {
             searching = false;
           }
           if (!wave_any(searching)) break;
-          RollOut rr = rollout<false>(alpha, searching);
-          if (searching) nro++;
-          if (searching) {
-            if (rr.limit) {
-              ls++;
-              alpha *= 0.5;
-            } else {
-              Jn = rr.J;
-              const double expected = -alpha * (dV1 + alpha * dV2);
-              zr = (expected > 0.0) ? (J_prev - Jn) / expected : -1.0;
-              ls++;
-              const bool again = ((zr <= o.line_search_lower_bound) || (zr > o.line_search_upper_bound)) &&
-                                 (Jn >= J_prev);
-              if (!again) {
-                searching = false;
-                accepted = true;
-                cm_n = rr.cmax;
-                g_n = rr.grad_new;
-              } else {
-                g_n = rr.grad_old;  // value used if the search ends in failure
-                alpha *= 0.5;
-              }
+          ALTRO_STAMP(ts = stamp();)
+          Trials T;
+          trial_costs(alpha, T);
+          ALTRO_STAMP(t_ls += stamp() - ts;)
+          const double a0 = alpha;
+          sfor<0, NA>([&](auto t) {
+            constexpr int Tt = decltype(t)::value;
+            if (searching && ls <= o.iterations_linesearch) {
+              ntr++;
+              trial(a0 * (1.0 / (double)(1 << Tt)), T.J[Tt], T.cmax[Tt], T.limit[Tt], T.unchanged[Tt]);
+              if (accepted && !searching) need_interp = true;
             }
-          }
+          });
         }
+        if (wave_any(need_interp)) {
+          ALTRO_STAMP(ts = stamp();)
+          interpolate(alpha, need_interp);
+          ALTRO_STAMP(t_ls += stamp() - ts;)
+        }
+        double dJ = 0.0;
+        bool cand = false;
         if (inner) {
           if (Jn > o.max_cost_value) {
             status = ALTRO_MAXIMUM_COST;
@@ -551,7 +892,7 @@ struct Solver {
           } else {
             if (accepted) cur ^= 1;  // copy_trajectories!
             cmax = cm_n;
-            const double dJ = fabs(Jn - J_prev);
+            dJ = fabs(Jn - J_prev);
             J_prev = Jn;
             J = Jn;
             if (iters < ALTRO_TRACE_LEN && j == 0) {
@@ -560,15 +901,26 @@ struct Solver {
             }
             iters++;
             dj_zero = (dJ == 0.0) ? dj_zero + 1 : 0;
-            if (dJ < cost_tol && g_n < grad_tol) {
-              inner = false;
-            } else if (iters >= o.iterations) {
-              status = ALTRO_MAX_ITERATIONS;
-              inner = false;
-            } else if (dj_zero > o.dJ_counter_limit) {
-              status = ALTRO_NO_PROGRESS;
-              inner = false;
-            }
+            cand = dJ < cost_tol;
+          }
+        }
+        // evaluate_convergence: (0 <= dJ < cost_tol) && grad < grad_tol -- the Todorov gradient
+        // is only evaluated for waves that hold a candidate
+        double grad = __builtin_inf();
+        if (wave_any(cand)) {
+          ALTRO_STAMP(ts = stamp();)
+          grad = todorov();
+          ALTRO_STAMP(t_td += stamp() - ts;)
+        }
+        if (inner) {
+          if (cand && grad < grad_tol) {
+            inner = false;
+          } else if (iters >= o.iterations) {
+            status = ALTRO_MAX_ITERATIONS;
+            inner = false;
+          } else if (dj_zero > o.dJ_counter_limit) {
+            status = ALTRO_NO_PROGRESS;
+            inner = false;
           }
         }
       }
@@ -592,12 +944,42 @@ struct Solver {
         }
       }
       if (wave_any(upd)) {
+        ALTRO_STAMP(ts = stamp();)
         dual_update(upd);
+        ALTRO_STAMP(t_du += stamp() - ts;)
         if (upd) mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
       }
     }
     if (has_con && status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance)
       status = ALTRO_SOLVE_SUCCEEDED;
+    nsolve++;
+    nit += iters;
+    nok += (status == ALTRO_SOLVE_SUCCEEDED) ? 1 : 0;
+  }
+
+  // Plant step of the MPC loop (random_linear_problem.jl:128-130):
+  //   x0 <- A x_1 + B u_1 + f + randn(n) * ||x0||_inf / 100
+  __device__ void plant_step(int step) {
+    double grow[NZ];
+    sfor<0, NZ>([&](auto c) {
+      constexpr int C = decltype(c)::value;
+      grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
+    });
+    const double z0 = ldg(P.Z, plane(cur) + at(0));
+    double acc4[4] = {ldg(P.fvec, rowoff), 0.0, 0.0, 0.0};
+    Blk<NX, NU>::GZ(acc4, z0, grow);
+    const double xn = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    const double nrm = row_max(is_x ? fabs(xn) : 0.0);
+    double nz = 0.0;
+    if (P.noise != nullptr && is_x) {
+      const int b = inst < P.B ? inst : P.B - 1;
+      nz = P.noise[((size_t)step * P.B + b) * NX + j];
+    }
+    x0 = is_x ? xn + nz * nrm / 100.0 : 0.0;
+  }
+
+  __device__ void finish() {
+    stg(P.x0, rowoff, x0);
     if (j == 0) {
       P.iters[inst] = iters;
       P.iters_outer[inst] = iters_outer;
@@ -608,15 +990,39 @@ struct Solver {
       P.cur[inst] = cur;
       P.n_backward[inst] += nbw;
       P.n_rollout[inst] += nro;
+      P.n_trials[inst] += ntr;
+      P.n_solves[inst] += nsolve;
+      P.n_iters[inst] += nit;
+      P.n_ok[inst] += nok;
     }
   }
 };
 
+// nsteps == 0: solve!(altro).  nsteps > 0: that many consecutive MPC steps of every instance,
+// each in the reference's order (random_linear_problem.jl:125-139,161): plant step + noise -> x0;
+// reference window <- step+1; shift_fill primal and dual; solve.
 template <int NX, int NU>
-__global__ void __launch_bounds__(64, 2) solve_kernel(SolveParams p) {
+__global__ void __launch_bounds__(64, ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double sm[IPW * LW * (LW + 1)];
+  const long long t0 = __builtin_amdgcn_s_memtime();
   Solver<NX, NU> s(p);
-  s.solve(sm);
+  const bool mpc = p.nsteps > 0;
+  const int n = mpc ? p.nsteps : 1;
+  for (int i = 0; i < n; ++i) {
+    if (mpc) {
+      const int step = p.first_step + i;
+      s.plant_step(step);
+      s.kref = step + 1;
+    }
+    s.solve(sm, mpc);
+  }
+  s.finish();
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    long long* wc = p.wave_cycles + (size_t)blockIdx.x * 8;
+    wc[0] = t1 - t0;
+    ALTRO_STAMP(wc[1] = s.t_bw; wc[2] = s.t_rc; wc[3] = s.t_ro; wc[4] = s.t_td; wc[5] = s.t_du; wc[6] = s.t_ls;)
+  }
 }
 
 }  // namespace altro

@@ -55,6 +55,13 @@ class BatchMPC:
         s._chk(s._L.altro_mpc_step_async(s.h, i))
         self.i = i + 1
 
+    def run_async(self, nsteps, first=None):
+        """nsteps consecutive MPC steps in one launch (altro_mpc_run_async)."""
+        first = self.i if first is None else first
+        s = self.solver
+        s._chk(s._L.altro_mpc_run_async(s.h, first, nsteps))
+        self.i = first + nsteps
+
     def synchronize(self):
         s = self.solver
         s._chk(s._L.altro_batch_synchronize(s.h))

@@ -77,7 +77,7 @@ def cpu_baseline(budget_s=12.0):
     import multiprocessing as mp
     cores = max(1, min(16, os.cpu_count() or 1))
     steps = 40
-    per = 400  # instances offered to each worker; it stops when the time budget is spent
+    per = 1500  # instances offered to each worker; it stops when the time budget is spent
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-per-launch", type=int, default=0,
+                    help="MPC steps per kernel launch in the timed region (0 = all K in one launch)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,10 +145,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    spl = a.steps_per_launch if a.steps_per_launch > 0 else K
     barrier()
     t0 = time.perf_counter()
-    for i in range(W, W + K):
-        mp.step_async(i)
+    i = W
+    while i < W + K:
+        n = min(spl, W + K - i)
+        mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
+        i += n
     mp.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -157,8 +163,10 @@ def main():
 
     st = altro.stats(mp.solver)
     ms = altro.timing_get(mp.solver)
-    nb, nr = altro.work_counters(mp.solver)
-    ok = int((st.status == altro.SOLVE_SUCCEEDED).sum())
+    nb, nr, ntr = altro.work_counters(mp.solver)
+    nsol, nit, nok = altro.solve_counters(mp.solver)
+    assert int(nsol.sum()) == B * K, (int(nsol.sum()), B * K)
+    ok = int(nok.sum())
 
     # final gather of the first controls (what an MPC consumer reads each tick)
     U1 = torch.from_numpy(altro.controls(mp.solver)[:, 0].copy()).cuda()
@@ -175,10 +183,11 @@ def main():
         value = solves / dt
         # roofline of the dominant kernel (solve_kernel): algorithmic flops of one launch =
         # sum over instances of the SURVEY 8(d) formula with the MEASURED pass counts
+        # (interpolated line-search trials do no rollout; they are not counted as flops)
         flops_launch = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N)) / max(1, len(ms))
         avg_ms = float(ms.mean()) if len(ms) else float("nan")
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-        bytes_launch = B * bytes_solve(n, m, N, 2 * m)
+        bytes_launch = B * K * bytes_solve(n, m, N, 2 * m) / max(1, len(ms))
         out = {
             "metric": "MPC solves/sec (batched iLQR to tol), random_linear_mpc n=12 m=4 N=50",
             "value": value,
@@ -204,9 +213,11 @@ def main():
                          "hbm_algorithmic_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
                          "hbm_frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
-            "solve_succeeded_frac": ok / (world * B),
-            "iterations_mean": float(st.iterations.mean()),
-            "iterations_hist": np.bincount(st.iterations).tolist(),
+            "steps_per_launch": spl,
+            "solve_succeeded_frac": ok / (world * B * K),
+            "iterations_mean": float(nit.sum() / (B * K)),
+            "iterations_hist_last_step": np.bincount(st.iterations).tolist(),
+            "interp_trials_per_solve": float(ntr.sum() / (B * K)),
             "backward_passes_per_solve": float(nb.sum() / (B * K)),
             "rollouts_per_solve": float(nr.sum() / (B * K)),
         }

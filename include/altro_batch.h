@@ -183,10 +183,19 @@ int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms);
  * reset also clears the work counters below.  Synchronises the stream. */
 int32_t altro_batch_timing_reset(altro_handle* h);
 int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count);
-/* Work done since the last timing reset, per instance: iLQR backward passes and rollouts
- * (open-loop + line-search trials).  These are the measured counts SURVEY 8(d)'s flops_solve
- * formula is evaluated with.  Arrays of `batch` int64. */
-int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts);
+/* Work done since the last timing reset, per instance: iLQR backward passes, rollouts (open-loop
+ * + the alpha = 1 trial of every line search) and further line-search trials (evaluated without a
+ * rollout, DESIGN.md "Line search").  These are the measured counts SURVEY 8(d)'s flops_solve
+ * formula is evaluated with.  Arrays of `batch` int64; any pointer may be NULL. */
+int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts,
+                                      int64_t* trials);
+/* Per instance since the last timing reset: solves run, iLQR iterations, solves that ended
+ * SOLVE_SUCCEEDED.  Arrays of `batch` int64; any pointer may be NULL. */
+int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded);
+/* Diagnostic: s_memtime ticks each wave (4 instances) spent in the last solve launch, 8 int64 per
+ * wave: total, backward passes, closed-loop rollouts, open-loop rollouts, Todorov gradient,
+ * dual update, streaming line-search sweeps, 1 spare.  count = 8 * number of waves. */
+int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t capacity, int32_t* count);
 
 /* ---- device-resident MPC harness (reference random_linear_problem.jl:121-139, mpc.jl:11-47).
  * The reference's MPC loop runs on the host around solve!; for a batch that lives in HBM the
@@ -202,6 +211,12 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
  * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
  * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */
 int32_t altro_mpc_step_async(altro_handle* h, int32_t step);
+/* The same for `nsteps` consecutive steps first_step .. first_step+nsteps-1 in ONE launch.
+ * Instances are independent closed loops, so inside the launch each wavefront runs its own four
+ * instances through all the steps without waiting for the rest of the batch; results are
+ * bit-identical to nsteps calls of altro_mpc_step_async.  Per-step statistics are accumulated
+ * (altro_batch_get_solve_counters); altro_batch_get_stats reports the last step. */
+int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps);
 /* x0 currently installed: [batch][n] */
 int32_t altro_batch_get_initial_state(altro_handle* h, double* x0);
 

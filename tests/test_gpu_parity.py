@@ -149,6 +149,53 @@ def test_instance_results_do_not_depend_on_batch(oracle):
     assert np.array_equal(altro.states(mp1.solver)[0], Xall[5])
 
 
+def test_fused_multi_step_launch_is_bit_identical_to_single_steps():
+    """altro_mpc_run_async(first, n) == n calls of altro_mpc_step_async, bit for bit."""
+    B, S = 37, 9
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=13)
+    a = altro.mpc.BatchMPC(pb)
+    b = altro.mpc.BatchMPC(pb)
+    a.initial_solve()
+    b.initial_solve()
+    for i in range(S):
+        a.step(i)
+    b.run_async(4, first=0)
+    b.run_async(S - 4)
+    b.synchronize()
+    assert np.array_equal(altro.states(a.solver), altro.states(b.solver))
+    assert np.array_equal(altro.controls(a.solver), altro.controls(b.solver))
+    assert np.array_equal(altro.get_duals(a.solver), altro.get_duals(b.solver))
+    assert np.array_equal(a.x0(), b.x0())
+    sa, sb = altro.stats(a.solver), altro.stats(b.solver)
+    assert np.array_equal(sa.iterations, sb.iterations) and np.array_equal(sa.status, sb.status)
+    assert np.array_equal(sa.cost, sb.cost)
+    ns, ni, nok = altro.solve_counters(b.solver)
+    assert np.all(ns == S + 1) and np.all(nok == S + 1)
+
+
+def test_separate_shift_fill_call_equals_fused_shift(oracle):
+    """The reference's explicit call sequence (set_initial_state!, update_trajectory!,
+    RD.shift_fill!, Altro.shift_fill!, solve!) through the fine-grained C-ABI calls gives the
+    same result as the device-resident MPC step."""
+    B, S = 6, 3
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=17)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    sv = altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb), altro.SolverOptions(**REF_OPTS))
+    altro.solve(sv)
+    for i in range(S):
+        mp.step(i)
+        x0 = mp.x0()                       # plant step + noise, as computed on device
+        altro.set_initial_state(sv, x0)
+        Xr, Ur = pb.window(i + 1)
+        altro.update_trajectory(sv, Xr, Ur)
+        altro.shift_fill(sv, True, True)
+        altro.solve(sv)
+        assert np.array_equal(altro.states(sv), altro.states(mp.solver))
+        assert np.array_equal(altro.controls(sv), altro.controls(mp.solver))
+        assert np.array_equal(altro.get_duals(sv), altro.get_duals(mp.solver))
+
+
 def test_shift_fill_and_accessors_roundtrip():
     B = 5
     pb = altro.problems.gen_random_linear_batch(B, n=6, m=3, N=9, steps=1, seed=2)
