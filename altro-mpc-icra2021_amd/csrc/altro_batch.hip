@@ -353,7 +353,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
   const size_t row = Bp * LW;
   // the kernels address every array with 32-bit element offsets
-  if (2 * N * row * sizeof(double) >= (1ull << 32) || (N - 1) * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
+  if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || (N - 1) * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
     g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
     altro_batch_destroy(h);
     return ALTRO_ERR_UNSUPPORTED;
@@ -366,9 +366,10 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMalloc(&h->zmin, LW * sizeof(double)));
   CCHK(hipMalloc(&h->zmax, LW * sizeof(double)));
   CCHK(hipMalloc(&h->x0, row * sizeof(double)));
-  CCHK(hipMalloc(&h->Z, 2 * N * row * sizeof(double)));
-  CCHK(hipMalloc(&h->Lhi, N * row * sizeof(double)));
-  CCHK(hipMalloc(&h->Llo, N * row * sizeof(double)));
+  // + one trash row at the end of each (stores of rows that sit out a phase land there)
+  CCHK(hipMalloc(&h->Z, (2 * N + 1) * row * sizeof(double)));
+  CCHK(hipMalloc(&h->Lhi, (N + 1) * row * sizeof(double)));
+  CCHK(hipMalloc(&h->Llo, (N + 1) * row * sizeof(double)));
   CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
   CCHK(hipMalloc(&h->KD, (N - 1) * Bp * m * LW * sizeof(double)));
   CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
@@ -393,9 +394,9 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 2 * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->Z, 0, 2 * N * row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Lhi, 0, N * row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Llo, 0, N * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Lhi, 0, (N + 1) * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Llo, 0, (N + 1) * row * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->KD, 0, (N - 1) * Bp * m * LW * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
   CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));

@@ -18,10 +18,18 @@
 //     indices are clamped instead of guarded, per-knot conditions are selects, stores are
 //     unconditional (into planes that are dead for the rows that do not need them).
 //   * the serial structure of the solve (AL outer loop / iLQR iterations / line search) and of
-//     the MPC loop around it (plant step, shift_fill, retarget, solve) runs inside the kernel with
-//     per-instance predicates; branches are wave-uniform (ballot), so EXEC is all ones wherever
-//     a DPP instruction executes.  Waves never synchronise with each other: instances are
-//     independent, so a wave that draws an easy instance simply moves on.
+//     the MPC loop around it (plant step, shift_fill, retarget, solve) runs inside the kernel as
+//     a PER-ROW STATE MACHINE: each of the four rows of a wave walks through its own
+//     (MPC step, AL outer iteration, iLQR iteration) sequence.  One turn of the wave loop runs,
+//     for whichever rows need it: [plant step + solve setup] -> [open-loop rollout] ->
+//     [backward pass, alpha = 1 rollout, line-search sweeps, convergence test] -> [dual update].
+//     A row that converges starts its next MPC step in the next turn while its wave-mates keep
+//     iterating, so a row never idles waiting for a slower neighbour (measured before this:
+//     56 wave-iterations per 42 instance-iterations).  Branches are wave-uniform (ballot), so
+//     EXEC is all ones wherever a DPP instruction executes; rows that sit out a phase have their
+//     stores redirected to a trash slot.  Waves never synchronise with each other.
+//   * row state (costs, tolerances, counters, phase) lives in LDS between phases, so that it
+//     does not occupy VGPRs during the register-hungry backward pass.
 //
 // Reference call sites served: solve!(altro) random_linear_problem.jl:113,161; the MPC update
 // sequence :121-139; algorithm restated from SURVEY.md Appendix A (rows P2-P12 of SURVEY 8a),
@@ -42,6 +50,12 @@
 #endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
+#endif
+#ifndef ALTRO_NA
+#define ALTRO_NA 4           // line-search step sizes evaluated per streaming sweep
+#endif
+#ifndef ALTRO_SYMMETRIZE
+#define ALTRO_SYMMETRIZE 0   // 1: S <- (S + S')/2 after every knot (as Altro.jl; costs 6 %)
 #endif
 #ifndef ALTRO_WAVES_PER_SIMD
 #define ALTRO_WAVES_PER_SIMD 2  // register budget: 512 / this
@@ -70,10 +84,10 @@ struct SolveParams {
   double* x0;            // [Bp][16]
   const double* Zref;    // [Nt][Bp][16]
   const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
-  double* Z;             // [2][N][Bp][16]  ping-pong trajectories
+  double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
   int* cur;              // [Bp] which plane of Z is current
-  double* Lhi;           // [N][Bp][16] duals of z - zmax <= 0
-  double* Llo;           // [N][Bp][16] duals of zmin - z <= 0
+  double* Lhi;           // [N+1][Bp][16] duals of z - zmax <= 0  (knot N = trash row)
+  double* Llo;           // [N+1][Bp][16] duals of zmin - z <= 0
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
   double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
   int* iters;
@@ -177,57 +191,63 @@ __device__ __forceinline__ void reg_update(double& rho, double& drho, const altr
   }
 }
 
+// Row state: everything the per-instance control flow of solve!() carries between phases.
+// One per row, in LDS (all 16 lanes of a row read the same words: LDS broadcast).
+enum { PH_STEP_BEGIN = 0, PH_OUTER_BEGIN = 1, PH_ITER = 2, PH_DONE = 3 };
+struct RowState {
+  double J, cmax, J_prev, rho, drho, mu, dV1, dV2, cost_tol, grad_tol;
+  int phase, status, iters, iters_outer, outer, it, dj_zero, cur, kref, step, shift, last;
+  int nbw, nro, nsolve, nit, nok, ntr;
+};
+
 template <int NX, int NU>
 struct Solver {
   static constexpr int NZ = NX + NU;
   static_assert(NZ <= LW, "packed kernel needs n + m <= 16");
 
   const SolveParams& P;
+  RowState* rs;  // this lane's row state (LDS)
+  double* sm;    // this row's 16 x 17 transpose tile (LDS)
   int lane, j, inst;
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
   unsigned kstride;  // Bp*16                 that every array stays below 2^32 bytes)
-  double wd, wf, zmin, zmax;
-  bool has_hi, has_lo;
-  double x0;
-  double mu;
-  int cur;
-  int kref;
-  // results of the last solve
-  int status, iters, iters_outer;
-  double J, cmax;
-  // accumulators over the launch
-  int nbw, nro, nsolve, nit, nok, ntr;
   ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls;)
 
-  __device__ Solver(const SolveParams& p) : P(p) {
+  struct LaneConst {
+    double wd, wf, zmin, zmax;
+    bool has_hi, has_lo;
+  };
+
+  __device__ Solver(const SolveParams& p, RowState* rows, double* tiles) : P(p) {
     lane = threadIdx.x & 63;
     j = lane & 15;
     inst = blockIdx.x * IPW + (lane >> 4);
+    rs = rows + (lane >> 4);
+    sm = tiles + (lane >> 4) * (LW * (LW + 1));
     is_x = j < NX;
     is_u = (j >= NX) && (j < NZ);
     rowoff = (unsigned)inst * LW + j;
     kstride = (unsigned)P.Bp * LW;
-    wd = P.wd[j];
-    wf = P.wf[j];
-    zmin = P.zmin[j];
-    zmax = P.zmax[j];
-    has_hi = zmax < 1e300;
-    has_lo = zmin > -1e300;
-    x0 = ldg(P.x0, rowoff);
-    cur = P.cur[inst];
-    mu = P.mu[inst];
-    kref = P.kref;
-    status = ALTRO_UNSOLVED;
-    iters = iters_outer = 0;
-    J = cmax = 0.0;
-    nbw = nro = nsolve = nit = nok = ntr = 0;
     ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
+  }
+
+  __device__ __forceinline__ LaneConst consts() const {
+    LaneConst c;
+    c.wd = P.wd[j];
+    c.wf = P.wf[j];
+    c.zmin = P.zmin[j];
+    c.zmax = P.zmax[j];
+    c.has_hi = c.zmax < 1e300;
+    c.has_lo = c.zmin > -1e300;
+    return c;
   }
 
   __device__ __forceinline__ unsigned at(int k) const { return (unsigned)k * kstride + rowoff; }
   // plane c of Z as an element offset (per instance: cur differs between rows)
   __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * kstride; }
+  __device__ __forceinline__ unsigned trash_z() const { return 2u * (unsigned)P.N * kstride + rowoff; }
+  __device__ __forceinline__ unsigned trash_l() const { return (unsigned)P.N * kstride + rowoff; }
   __device__ __forceinline__ bool box_at(int k) const { return k >= P.box_k0 && k <= P.box_k1; }
   __device__ __forceinline__ unsigned kd_at(int k, int row) const {
     return (((unsigned)k * P.Bp + inst) * NU + row) * LW + j;
@@ -244,16 +264,16 @@ struct Solver {
 
   // stage cost + box AL term of this lane's element; updates the lane's violation maximum.
   // Branch-free: box_on only selects.  (oracle total_cost / con_cost; TO.jl cost! -- SURVEY A.2)
-  __device__ __forceinline__ double lane_cost(double z, double zr, double w, double lhi, double llo,
-                                              bool box_on, double& viol) const {
+  static __device__ __forceinline__ double lane_cost(const LaneConst& c, double mu, double z, double zr, double w,
+                                                     double lhi, double llo, bool box_on, double& viol) {
     const double e = z - zr;
     double Jl = 0.5 * w * e * e;
-    const double chi = z - zmax, clo = zmin - z;
-    const bool ahi = (chi >= 0.0) || (lhi > 0.0);
-    const bool alo = (clo >= 0.0) || (llo > 0.0);
+    const double chi = z - c.zmax, clo = c.zmin - z;
+    const bool ahi = (chi >= 0.0) | (lhi > 0.0);
+    const bool alo = (clo >= 0.0) | (llo > 0.0);
     const double Jhi = lhi * chi + (ahi ? 0.5 * mu * chi * chi : 0.0);
     const double Jlo = llo * clo + (alo ? 0.5 * mu * clo * clo : 0.0);
-    const bool bh = box_on && has_hi, bl = box_on && has_lo;
+    const bool bh = box_on & c.has_hi, bl = box_on & c.has_lo;
     Jl += bh ? Jhi : 0.0;
     Jl += bl ? Jlo : 0.0;
     viol = fmax(viol, bh ? chi : 0.0);
@@ -273,18 +293,20 @@ struct Solver {
   };
 
   // rollout!(solver[, alpha]) fused with cost!(obj, Z̄) and max_violation.
-  //   OPEN : open-loop rollout of plane `cur` from x0 (iLQR initialize!), in place.  With SHIFT
-  //          the controls and box duals are read one knot ahead and written back in place:
+  //   OPEN : open-loop rollout of plane `cur` from x0 (iLQR initialize!), in place.  Rows with
+  //          `shift` read the controls and box duals one knot ahead and write them back in place:
   //          RD.shift_fill!(Z) + Altro.shift_fill!(conSet) folded into the same sweep
-  //          (random_linear_problem.jl:136,139).
-  //   !OPEN: closed-loop rollout with gains KD and step alpha from plane cur into plane cur^1
-  //          (dead storage for every row that is not line-searching, so stores need no mask).
-  //   PRED : stores masked by `store` (open rollouts of waves that hold a finished instance,
-  //          whose plane must stay bit-identical); the fast variants store unconditionally.
-  template <bool OPEN, bool SHIFT, bool PRED>
-  __device__ RollOut rollout(double alpha, bool store) {
+  //          (random_linear_problem.jl:136,139).  Rows with !take (they are in the middle of an
+  //          inner loop) send their stores to the trash slot.
+  //   !OPEN: closed-loop rollout with gains KD and step alpha = 1 from plane cur into plane
+  //          cur^1 (dead storage for every row that is not iterating, so stores need no mask).
+  template <bool OPEN>
+  __device__ RollOut rollout(bool take, bool shift) {
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const int cur = rs->cur, kref = rs->kref;
     const unsigned zs = plane(cur);
-    const unsigned zd = OPEN ? plane(cur) : plane(cur ^ 1);
+    const unsigned zd = OPEN ? (take ? plane(cur) : trash_z() - 0u) : plane(cur ^ 1);
     const int N = P.N;
     double grow[NZ];
     sfor<0, NZ>([&](auto c) {
@@ -292,19 +314,23 @@ struct Solver {
       grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
     });
     const double fv = ldg(P.fvec, rowoff);
-    double xb = x0;
+    double xb = ldg(P.x0, rowoff);
     double Jacc = 0.0, viol = 0.0;
     bool limit = false, changed = false;
     const int k1 = P.box_k1;
+    const bool shl = OPEN && shift;           // per row
+    const bool shu = shl && !is_x;            // controls are read one knot ahead
+    const bool wr_l = OPEN && shift && take;  // shifted duals are written back
 
     // operands of stage knot k (k clamped to 0..N-2 by the callers)
     auto load = [&](int k, KnotIn& in) {
-      const int ku = SHIFT ? imin(k + 1, N - 2) : k;            // controls one knot ahead
-      const int kl = SHIFT ? imax(imin(k + 1, k1), 0) : k;       // duals one knot ahead
-      in.z = ldg(P.Z, zs + at((SHIFT && !is_x) ? ku : k));
+      const int ku = imin(k + 1, N - 2);
+      const int kl = imax(imin(k + 1, k1), 0);
+      in.z = ldg(P.Z, zs + at(shu ? ku : k));
       in.zr = ldg(P.Zref, at(kref + k));
-      in.lhi = ldg(P.Lhi, at(kl));
-      in.llo = ldg(P.Llo, at(kl));
+      const unsigned li = at(shl ? kl : k);
+      in.lhi = ldg(P.Lhi, li);
+      in.llo = ldg(P.Llo, li);
       if constexpr (!OPEN) {
         sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
       }
@@ -316,15 +342,10 @@ struct Solver {
       double zb;
       if constexpr (OPEN) {
         zb = is_x ? xb : in.z;
-        if constexpr (PRED) {
-          if (store) stg(P.Z, zd + at(k), zb);
-        } else {
-          stg(P.Z, zd + at(k), zb);
-        }
-        if constexpr (SHIFT) {
-          stg(P.Lhi, at(k), lhi);
-          stg(P.Llo, at(k), llo);
-        }
+        stg(P.Z, take ? (zd + at(k)) : trash_z(), zb);
+        const unsigned li = wr_l ? at(k) : trash_l();
+        stg(P.Lhi, li, lhi);
+        stg(P.Llo, li, llo);
       } else {
         // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
         const double dx = is_x ? (xb - in.z) : 0.0;
@@ -344,14 +365,14 @@ struct Solver {
           du = (j == NX + A) ? da : du;
           dff = (j == NX + A) ? in.kcol[A] : dff;
         });
-        const double ub = in.z + du + alpha * dff;
+        const double ub = in.z + du + dff;  // alpha = 1
         zb = is_x ? xb : ub;
-        changed = changed || ((is_x || is_u) && (zb != in.z));
+        changed = changed | ((is_x | is_u) & (zb != in.z));
         stg(P.Z, zd + at(k), zb);
       }
-      Jacc += lane_cost(zb, in.zr, wd, lhi, llo, bx, viol);
+      Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
       const double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
-      limit = limit || ((is_x || is_u) && !(fabs(zb) <= lim));
+      limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
       Blk<NX, NU>::GZ(acc4, zb, grow);
       xb = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
@@ -391,14 +412,11 @@ struct Solver {
     {  // terminal knot: state only
       const bool bx = box_at(kt);
       const double zb = is_x ? xb : 0.0;
-      if constexpr (PRED) {
-        if (store) stg(P.Z, zd + at(kt), zb);
-      } else {
-        stg(P.Z, zd + at(kt), zb);
-      }
-      Jacc += lane_cost(zb, t_zr, wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx && is_x, viol);
-      limit = limit || (is_x && !(fabs(zb) <= P.o.max_state_value));
-      if constexpr (!OPEN) changed = changed || (is_x && (zb != t_z));
+      if constexpr (OPEN) stg(P.Z, take ? (zd + at(kt)) : trash_z(), zb);
+      else stg(P.Z, zd + at(kt), zb);
+      Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
+      limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
+      if constexpr (!OPEN) changed = changed | (is_x & (zb != t_z));
     }
     RollOut r;
     r.J = row_sum(Jacc);
@@ -411,7 +429,7 @@ struct Solver {
   // gradient_todorov!: mean_k max_a |d_k,a| / (|u_k,a| + 1) on the current plane.  Evaluated
   // lazily: the reference only uses it in the convergence test, which also needs dJ < tol.
   __device__ double todorov() {
-    const unsigned zs = plane(cur);
+    const unsigned zs = plane(rs->cur);
     const int N = P.N;
     const int ra = is_u ? (j - NX) : 0;
     double acc = 0.0;
@@ -443,13 +461,16 @@ struct Solver {
   // Plane cur^1 holds Z̄(1) from the alpha = 1 rollout.  trial_costs evaluates cost!, the
   // violation, the state/control limits and the "reproduces Z bit for bit" test for NA
   // consecutive step sizes alpha, alpha/2, ... in ONE streaming sweep (no gains, no serial chain).
-  static constexpr int NA = 4;
+  static constexpr int NA = ALTRO_NA;
   struct Trials {
     double J[NA], cmax[NA];
     bool limit[NA], unchanged[NA];
   };
 
   __device__ void trial_costs(double alpha, Trials& T) {
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const int cur = rs->cur, kref = rs->kref;
     const unsigned zs = plane(cur);
     const unsigned z1 = plane(cur ^ 1);
     const int N = P.N;
@@ -464,7 +485,7 @@ struct Solver {
       chg[Tt] = false;
       a[Tt] = alpha * (1.0 / (double)(1 << Tt));
     });
-    const bool live = is_x || is_u;
+    const bool live = is_x | is_u;
     const double lm = is_x ? P.o.max_state_value : P.o.max_control_value;
     constexpr int UN = ALTRO_UN;
     const int nch = (N + UN - 1) / UN;
@@ -485,17 +506,17 @@ struct Solver {
         const int k = k0 + Q;
         const bool valid = k < N;
         const bool term = (k >= N - 1);
-        const bool bx = box_at(k) && valid;
+        const bool bx = box_at(k) & valid;
         const double dz = zz1[Q] - z[Q];
-        const double w = valid ? (term ? wf : wd) : 0.0;
-        const bool on = (term ? is_x : live) && valid;
+        const double w = valid ? (term ? lc.wf : lc.wd) : 0.0;
+        const bool on = (term ? is_x : live) & valid;
         const double lh = bx ? lhi[Q] : 0.0, ll = bx ? llo[Q] : 0.0;
         sfor<0, NA>([&](auto t) {
           constexpr int Tt = decltype(t)::value;
           const double zb = on ? __builtin_fma(a[Tt], dz, z[Q]) : 0.0;
-          Jacc[Tt] += lane_cost(zb, on ? zr[Q] : 0.0, w, lh, ll, bx && on, viol[Tt]);
-          lim[Tt] = lim[Tt] || (on && !(fabs(zb) <= lm));
-          chg[Tt] = chg[Tt] || (on && (zb != z[Q]));
+          Jacc[Tt] += lane_cost(lc, mu, zb, on ? zr[Q] : 0.0, w, lh, ll, bx & on, viol[Tt]);
+          lim[Tt] = lim[Tt] | (on & !(fabs(zb) <= lm));
+          chg[Tt] = chg[Tt] | (on & (zb != z[Q]));
         });
       });
     }
@@ -508,8 +529,9 @@ struct Solver {
     });
   }
 
-  // Z̄ <- Z + alpha (Z̄(1) - Z) in plane cur^1, for the instances flagged `doit`
+  // Z̄ <- Z + alpha (Z̄(1) - Z) in plane cur^1, for the rows flagged `doit`
   __device__ void interpolate(double alpha, bool doit) {
+    const int cur = rs->cur;
     const unsigned zs = plane(cur);
     const unsigned z1 = plane(cur ^ 1);
     const int N = P.N;
@@ -527,26 +549,26 @@ struct Solver {
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = k0 + Q;
-        const bool on = (k >= N - 1) ? is_x : (is_x || is_u);
+        const bool on = (k >= N - 1) ? is_x : (is_x | is_u);
         const double zb = on ? __builtin_fma(alpha, zz1[Q] - z[Q], z[Q]) : 0.0;
-        if (doit && k < N) stg(P.Z, z1 + at(k), zb);
+        stg(P.Z, (doit & (k < N)) ? (z1 + at(imin(k, N - 1))) : trash_z(), zb);
       });
     }
   }
 
   // gradient / Gauss-Newton hessian of the box AL term of this lane's element (branch-free)
-  __device__ __forceinline__ void box_expand(double z, double lhi, double llo, bool on, double& qz,
-                                             double& hz) const {
-    const double chi = z - zmax, clo = zmin - z;
-    const bool ahi = (chi >= 0.0) || (lhi > 0.0);
-    const bool alo = (clo >= 0.0) || (llo > 0.0);
+  static __device__ __forceinline__ void box_expand(const LaneConst& c, double mu, double z, double lhi, double llo,
+                                                    bool on, double& qz, double& hz) {
+    const double chi = z - c.zmax, clo = c.zmin - z;
+    const bool ahi = (chi >= 0.0) | (lhi > 0.0);
+    const bool alo = (clo >= 0.0) | (llo > 0.0);
     const double ghi = lhi + (ahi ? mu * chi : 0.0);
     const double glo = llo + (alo ? mu * clo : 0.0);
-    const bool bh = on && has_hi, bl = on && has_lo;
+    const bool bh = on & c.has_hi, bl = on & c.has_lo;
     qz += bh ? ghi : 0.0;
-    hz += (bh && ahi) ? mu : 0.0;
+    hz += (bh & ahi) ? mu : 0.0;
     qz -= bl ? glo : 0.0;
-    hz += (bl && alo) ? mu : 0.0;
+    hz += (bl & alo) ? mu : 0.0;
   }
 
   // backwardpass! (SURVEY A.3 / oracle backward_pass): Riccati recursion over plane `cur`,
@@ -561,8 +583,12 @@ struct Solver {
   // Quu_reg is factored as L D L' (no square roots; pivots D_j > 0 is the same PD test as
   // Cholesky's).  RHO = false is the rho == 0 instantiation (every convex run).
   template <bool RHO>
-  __device__ void backward(double rho, double& dV1, double& dV2, bool& fail, double* sm) {
-    const unsigned zs = plane(cur);
+  __device__ void backward(double& dV1, double& dV2, bool& fail) {
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const double rho = RHO ? rs->rho : 0.0;
+    const int kref = rs->kref;
+    const unsigned zs = plane(rs->cur);
     double g[NX];
     sfor<0, NX>([&](auto c) {
       constexpr int C = decltype(c)::value;
@@ -576,8 +602,8 @@ struct Solver {
       const double z = ldg(P.Z, zs + at(k));
       const double zr = ldg(P.Zref, at(kref + k));
       const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
-      double qz = wf * (z - zr), hz = wf;
-      box_expand(z, lhi, llo, box_at(k) && is_x, qz, hz);
+      double qz = lc.wf * (z - zr), hz = lc.wf;
+      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz);
       sfor<0, NX>([&](auto c) {
         constexpr int C = decltype(c)::value;
         Sx[C] = (j == C) ? hz : 0.0;
@@ -587,17 +613,17 @@ struct Solver {
     dV1 = 0.0;
     dV2 = 0.0;
     fail = false;
-    double* my = sm + (lane >> 4) * (LW * (LW + 1));
+    double* my = sm;
     // operands of the knot about to be processed (loaded one knot ahead)
     double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
     double lhi = ldg(P.Lhi, at(N - 2)), llo = ldg(P.Llo, at(N - 2));
-    for (int k = N - 2; k >= 0; --k) {   // body: one basic block
+    for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + at(km));
       const double zrn = ldg(P.Zref, at(kref + km));
       const double lhin = ldg(P.Lhi, at(km)), llon = ldg(P.Llo, at(km));
-      double qz = wd * (z - zr), hz = wd;
-      box_expand(z, lhi, llo, box_at(k), qz, hz);
+      double qz = lc.wd * (z - zr), hz = lc.wd;
+      box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
       double w[NX + 1];
       sfor<0, NX + 1>([&](auto c) { w[decltype(c)::value] = 0.0; });
@@ -630,7 +656,7 @@ struct Solver {
           constexpr int Kk = decltype(kk)::value;
           dd -= L[Jc][Kk] * Ld[Jc][Kk];
         });
-        fail = fail || !(dd > 0.0);
+        fail = fail | !(dd > 0.0);
         dinv[Jc] = rcp_nr(dd);
         sfor<Jc + 1, NU>([&](auto ii) {
           constexpr int I = decltype(ii)::value;
@@ -695,10 +721,11 @@ struct Solver {
       } else {
         Blk<NX, NU>::CTG0(h, kd, r);
       }
-      // transpose through LDS.  The workgroup is ONE wave and each instance has its own LDS
-      // region, so no s_barrier is needed: LDS operations of a wave execute in issue order.
-      // Lanes >= NX read rows that were never written and carry garbage columns from here on;
-      // nothing ever reads a column of a lane >= NX (the DPP broadcasts only source lanes < NX).
+      // transpose through LDS.  The workgroup is ONE wave and each row has its own tile, so no
+      // s_barrier is needed: LDS operations of a wave execute in issue order.  Lanes >= NX read
+      // rows that were never written and carry garbage columns from here on; nothing ever reads
+      // a column of a lane >= NX (the DPP broadcasts only source lanes < NX).
+#if ALTRO_SYMMETRIZE
       sfor<0, NX>([&](auto c) {
         constexpr int C = decltype(c)::value;
         my[C * (LW + 1) + j] = h[C];
@@ -710,6 +737,9 @@ struct Solver {
         Sx[C] = 0.5 * (h[C] + st);
       });
       __builtin_amdgcn_wave_barrier();
+#else
+      sfor<0, NX>([&](auto c) { Sx[decltype(c)::value] = h[decltype(c)::value]; });
+#endif
       Sx[NX] = snew;
       z = zn;
       zr = zrn;
@@ -720,280 +750,356 @@ struct Solver {
 
   // dual_update! for the box rows of plane `cur` (penalty_update! is the caller's mu *= phi)
   __device__ void dual_update(bool upd) {
-    const unsigned zs = plane(cur);
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const unsigned zs = plane(rs->cur);
     const double dmax = P.o.dual_max;
     for (int k = P.box_k0; k <= P.box_k1; ++k) {
-      const bool on = (k < P.N - 1) ? (is_x || is_u) : is_x;
+      const bool on = (k < P.N - 1) ? (is_x | is_u) : is_x;
       const double z = ldg(P.Z, zs + at(k));
       const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
-      const double nhi = fmin(fmax(lhi + mu * (z - zmax), 0.0), dmax);
-      const double nlo = fmin(fmax(llo + mu * (zmin - z), 0.0), dmax);
-      if (upd && on && has_hi) stg(P.Lhi, at(k), nhi);
-      if (upd && on && has_lo) stg(P.Llo, at(k), nlo);
+      const double nhi = fmin(fmax(lhi + mu * (z - lc.zmax), 0.0), dmax);
+      const double nlo = fmin(fmax(llo + mu * (lc.zmin - z), 0.0), dmax);
+      stg(P.Lhi, (upd & on & lc.has_hi) ? at(k) : trash_l(), nhi);
+      stg(P.Llo, (upd & on & lc.has_lo) ? at(k) : trash_l(), nlo);
     }
   }
 
-  // solve!(::ALTROSolver) -> AL outer loop -> iLQR (oracle orc_solve).
-  // `shift`: fold shift_fill! of controls and duals into the first open-loop rollout.
-  __device__ void solve(double* sm, bool shift) {
-    const altro_opts& o = P.o;
-    const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
-    const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
-    if (o.reset_penalties) mu = mu0;
-    if (o.reset_duals) {  // initialize!: lambda <- 0
-      for (int k = P.box_k0; k <= P.box_k1; ++k) {
-        stg(P.Lhi, at(k), 0.0);
-        stg(P.Llo, at(k), 0.0);
-      }
-    }
-    status = ALTRO_UNSOLVED;
-    iters = 0;
-    iters_outer = 0;
-    bool alive = true;
-    J = 0.0;
-    cmax = 0.0;
-    const bool has_con = P.box_k1 >= P.box_k0;
-    const int n_outer = has_con ? o.iterations_outer : 1;
-
-    for (int outer = 0; outer < n_outer; ++outer) {
-      if (!wave_any(alive)) break;
-      const bool last = (outer == n_outer - 1);
-      const double cost_tol = (!last && has_con) ? o.cost_tolerance_intermediate : o.cost_tolerance;
-      const double grad_tol = (!last && has_con) ? o.gradient_tolerance_intermediate : o.gradient_tolerance;
-      // ---------------- iLQR solve
-      double rho = o.bp_reg_initial, drho = 0.0;
-      int dj_zero = 0;
-      bool inner = alive;
-      ALTRO_STAMP(long long ts = stamp();)
-      // every row alive: in-place open rollout with unconditional stores; a finished row's plane
-      // must stay bit-identical, so waves that hold one take the predicated variant
-      RollOut r0;
-      if (!wave_any(!alive)) {
-        if (shift && outer == 0) r0 = rollout<true, true, false>(0.0, true);
-        else r0 = rollout<true, false, false>(0.0, true);
-      } else {
-        r0 = rollout<true, false, true>(0.0, inner);
-      }
-      ALTRO_STAMP(t_ro += stamp() - ts;)
-      if (inner) nro++;
-      double J_prev = r0.J;
-      if (inner) {
-        J = r0.J;
-        cmax = r0.cmax;
-      }
-      if (inner && r0.limit) {
-        status = ALTRO_STATE_LIMIT;
-        J = __builtin_inf();
-        cmax = __builtin_inf();
-        inner = false;
-      }
-      for (int it = 0; it < o.iterations_inner; ++it) {
-        if (!wave_any(inner)) break;
-        double dV1, dV2;
-        // backward pass (with regularisation restarts)
-        while (true) {
-          bool fail;
-          ALTRO_STAMP(ts = stamp();)
-          if (wave_any(rho != 0.0)) backward<true>(rho, dV1, dV2, fail, sm);
-          else backward<false>(rho, dV1, dV2, fail, sm);
-          ALTRO_STAMP(t_bw += stamp() - ts;)
-          if (inner) nbw++;
-          fail = row_any(fail, lane) && inner;
-          if (fail) {
-            if (rho >= o.bp_reg_max) {
-              status = ALTRO_NO_PROGRESS;
-              inner = false;
-            } else {
-              reg_update(rho, drho, o, true);
-            }
-          }
-          if (!wave_any(fail && inner)) {
-            if (!fail) reg_update(rho, drho, o, false);
-            break;
-          }
-        }
-        // forward pass: line search on alpha (forwardpass!).  Trial 0 (alpha = 1) is
-        // the closed-loop rollout; later trials are evaluated by interpolation, NA per sweep.
-        double alpha = 1.0, zr = -1.0, Jn = __builtin_inf(), cm_n = cmax;
-        int ls = 0;
-        bool searching = inner, accepted = false, need_interp = false;
-        // one trial of the reference loop body for an instance that is still searching
-        auto trial = [&](double a_t, double J_t, double cm_t, bool lim_t, bool unch_t) {
-          if (lim_t) {
-            ls++;
-            alpha = 0.5 * a_t;
-            return;
-          }
-          Jn = J_t;
-          const double expected = -a_t * (dV1 + a_t * dV2);
-          zr = (expected > 0.0) ? (J_prev - Jn) / expected : -1.0;
-          ls++;
-          const bool again = ((zr <= o.line_search_lower_bound) || (zr > o.line_search_upper_bound)) &&
-                             (Jn >= J_prev);
-          if (!again) {
-            searching = false;
-            accepted = true;
-            cm_n = cm_t;
-            alpha = a_t;
-          } else {
-            alpha = 0.5 * a_t;
-            // Exact early-out: if this trial reproduced the current trajectory bit for bit, every
-            // smaller alpha reproduces it too (round-to-nearest is monotone), J stays == J_prev,
-            // and the reference loop would spin to iterations_linesearch and fail.  Jump there.
-            if (unch_t) ls = o.iterations_linesearch + 1;
-          }
-        };
-        {
-          ALTRO_STAMP(ts = stamp();)
-          RollOut rr = rollout<false, false, false>(1.0, true);
-          ALTRO_STAMP(t_rc += stamp() - ts;)
-          if (searching) {
-            nro++;
-            trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged);
-          }
-        }
-        while (true) {
-          const bool failnow = searching && (ls > o.iterations_linesearch);
-          if (failnow) {
-            Jn = J_prev;
-            cm_n = cmax;
-            alpha = 0.0;
-            reg_update(rho, drho, o, true);
-            rho += o.bp_reg_fp;
-            searching = false;
-          }
-          if (!wave_any(searching)) break;
-          ALTRO_STAMP(ts = stamp();)
-          Trials T;
-          trial_costs(alpha, T);
-          ALTRO_STAMP(t_ls += stamp() - ts;)
-          const double a0 = alpha;
-          sfor<0, NA>([&](auto t) {
-            constexpr int Tt = decltype(t)::value;
-            if (searching && ls <= o.iterations_linesearch) {
-              ntr++;
-              trial(a0 * (1.0 / (double)(1 << Tt)), T.J[Tt], T.cmax[Tt], T.limit[Tt], T.unchanged[Tt]);
-              if (accepted && !searching) need_interp = true;
-            }
-          });
-        }
-        if (wave_any(need_interp)) {
-          ALTRO_STAMP(ts = stamp();)
-          interpolate(alpha, need_interp);
-          ALTRO_STAMP(t_ls += stamp() - ts;)
-        }
-        double dJ = 0.0;
-        bool cand = false;
-        if (inner) {
-          if (Jn > o.max_cost_value) {
-            status = ALTRO_MAXIMUM_COST;
-            J = Jn;
-            inner = false;
-          } else {
-            if (accepted) cur ^= 1;  // copy_trajectories!
-            cmax = cm_n;
-            dJ = fabs(Jn - J_prev);
-            J_prev = Jn;
-            J = Jn;
-            if (iters < ALTRO_TRACE_LEN && j == 0) {
-              P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + iters] = J;
-              P.ctrace[(size_t)inst * ALTRO_TRACE_LEN + iters] = cmax;
-            }
-            iters++;
-            dj_zero = (dJ == 0.0) ? dj_zero + 1 : 0;
-            cand = dJ < cost_tol;
-          }
-        }
-        // evaluate_convergence: (0 <= dJ < cost_tol) && grad < grad_tol -- the Todorov gradient
-        // is only evaluated for waves that hold a candidate
-        double grad = __builtin_inf();
-        if (wave_any(cand)) {
-          ALTRO_STAMP(ts = stamp();)
-          grad = todorov();
-          ALTRO_STAMP(t_td += stamp() - ts;)
-        }
-        if (inner) {
-          if (cand && grad < grad_tol) {
-            inner = false;
-          } else if (iters >= o.iterations) {
-            status = ALTRO_MAX_ITERATIONS;
-            inner = false;
-          } else if (dj_zero > o.dJ_counter_limit) {
-            status = ALTRO_NO_PROGRESS;
-            inner = false;
-          }
-        }
-      }
-      // ---------------- AL outer update
-      bool upd = false;
-      if (alive) {
-        if (has_con) iters_outer++;
-        if (!has_con) {
-          if (status == ALTRO_UNSOLVED) status = ALTRO_SOLVE_SUCCEEDED;
-          cmax = 0.0;
-          alive = false;
-        } else if (status > ALTRO_SOLVE_SUCCEEDED) {
-          alive = false;
-        } else if (cmax < o.constraint_tolerance || mu >= o.penalty_max) {
-          alive = false;
-        } else if (last) {
-          status = ALTRO_MAX_ITERATIONS_OUTER;
-          alive = false;
-        } else {
-          upd = true;
-        }
-      }
-      if (wave_any(upd)) {
-        ALTRO_STAMP(ts = stamp();)
-        dual_update(upd);
-        ALTRO_STAMP(t_du += stamp() - ts;)
-        if (upd) mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
-      }
-    }
-    if (has_con && status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance)
-      status = ALTRO_SOLVE_SUCCEEDED;
-    nsolve++;
-    nit += iters;
-    nok += (status == ALTRO_SOLVE_SUCCEEDED) ? 1 : 0;
-  }
-
-  // Plant step of the MPC loop (random_linear_problem.jl:128-130):
+  // Plant step of the MPC loop (random_linear_problem.jl:128-130) for the rows flagged `doit`:
   //   x0 <- A x_1 + B u_1 + f + randn(n) * ||x0||_inf / 100
-  __device__ void plant_step(int step) {
+  __device__ void plant_step(bool doit, int step) {
     double grow[NZ];
     sfor<0, NZ>([&](auto c) {
       constexpr int C = decltype(c)::value;
       grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
     });
-    const double z0 = ldg(P.Z, plane(cur) + at(0));
+    const double z0 = ldg(P.Z, plane(rs->cur) + at(0));
     double acc4[4] = {ldg(P.fvec, rowoff), 0.0, 0.0, 0.0};
     Blk<NX, NU>::GZ(acc4, z0, grow);
     const double xn = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     const double nrm = row_max(is_x ? fabs(xn) : 0.0);
     double nz = 0.0;
-    if (P.noise != nullptr && is_x) {
+    if (P.noise != nullptr && is_x && doit) {
       const int b = inst < P.B ? inst : P.B - 1;
       nz = P.noise[((size_t)step * P.B + b) * NX + j];
     }
-    x0 = is_x ? xn + nz * nrm / 100.0 : 0.0;
+    const double x0n = is_x ? xn + nz * nrm / 100.0 : 0.0;
+    if (doit) stg(P.x0, rowoff, x0n);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // The wave loop: solve!(::ALTROSolver) -> AL outer loop -> iLQR (oracle
+  // orc_solve) and the MPC step sequence around it (random_linear_problem.jl:125-139,161), as a
+  // per-row state machine.  mpc: nsteps consecutive MPC steps per row; else one plain solve!().
+  __device__ void run(bool mpc, int first_step, int nsteps) {
+    const altro_opts& o = P.o;
+    const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
+    const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
+    const bool has_con = P.box_k1 >= P.box_k0;
+    const int n_outer = has_con ? o.iterations_outer : 1;
+    {  // row state init (every lane of the row writes the same words)
+      RowState s;
+      s.J = s.cmax = s.J_prev = s.rho = s.drho = s.dV1 = s.dV2 = s.cost_tol = s.grad_tol = 0.0;
+      s.mu = P.mu[inst];
+      s.phase = PH_STEP_BEGIN;
+      s.status = ALTRO_UNSOLVED;
+      s.iters = s.iters_outer = s.outer = s.it = s.dj_zero = s.shift = s.last = 0;
+      s.cur = P.cur[inst];
+      s.kref = P.kref;
+      s.step = 0;
+      s.nbw = s.nro = s.nsolve = s.nit = s.nok = s.ntr = 0;
+      *rs = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+      // ---------------- A. rows that begin a solve (one per MPC step, or the single plain solve)
+      {
+        const int ph = rs->phase;
+        const bool begin = ph == PH_STEP_BEGIN;
+        if (wave_any(begin)) {
+          const int stp = rs->step;
+          const bool go = begin && (stp < (mpc ? nsteps : 1));
+          if (mpc && wave_any(go)) plant_step(go, first_step + stp);
+          if (o.reset_duals && wave_any(go)) {  // initialize!: lambda <- 0
+            for (int k = P.box_k0; k <= P.box_k1; ++k) {
+              stg(P.Lhi, go ? at(k) : trash_l(), 0.0);
+              stg(P.Llo, go ? at(k) : trash_l(), 0.0);
+            }
+          }
+          if (begin) {
+            if (go) {
+              if (mpc) rs->kref = first_step + stp + 1;  // update_trajectory!(obj, Z_track, k_mpc)
+              if (o.reset_penalties) rs->mu = mu0;
+              rs->status = ALTRO_UNSOLVED;
+              rs->iters = 0;
+              rs->iters_outer = 0;
+              rs->outer = 0;
+              rs->J = 0.0;
+              rs->cmax = 0.0;
+              rs->shift = mpc ? 1 : 0;
+              rs->phase = PH_OUTER_BEGIN;
+            } else {
+              rs->phase = PH_DONE;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!wave_any(rs->phase != PH_DONE)) break;
+
+      // ---------------- B. rows that begin an iLQR solve: open-loop rollout (initialize!)
+      {
+        const bool ob = rs->phase == PH_OUTER_BEGIN;
+        if (wave_any(ob)) {
+          ALTRO_STAMP(long long ts = stamp();)
+          const RollOut r0 = rollout<true>(ob, ob && rs->shift != 0);
+          ALTRO_STAMP(t_ro += stamp() - ts;)
+          if (ob) {
+            const int outer = rs->outer;
+            const bool last = (outer == n_outer - 1);
+            rs->last = last ? 1 : 0;
+            rs->cost_tol = (!last && has_con) ? o.cost_tolerance_intermediate : o.cost_tolerance;
+            rs->grad_tol = (!last && has_con) ? o.gradient_tolerance_intermediate : o.gradient_tolerance;
+            rs->rho = o.bp_reg_initial;
+            rs->drho = 0.0;
+            rs->dj_zero = 0;
+            rs->it = 0;
+            rs->shift = 0;
+            rs->nro += 1;
+            rs->J_prev = r0.J;
+            rs->J = r0.J;
+            rs->cmax = r0.cmax;
+            rs->phase = PH_ITER;
+            if (r0.limit) {
+              rs->status = ALTRO_STATE_LIMIT;
+              rs->J = __builtin_inf();
+              rs->cmax = __builtin_inf();
+              rs->it = o.iterations_inner;  // skip the inner loop: falls through to the AL update
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ---------------- C. one iLQR iteration for the rows inside their inner loop
+      bool upd = false;  // rows that need a dual update after this turn
+      {
+        bool inner = (rs->phase == PH_ITER) && (rs->it < o.iterations_inner) && (rs->status <= ALTRO_SOLVE_SUCCEEDED);
+        bool inner_end = (rs->phase == PH_ITER) && !inner;  // loop exhausted / aborted before this turn
+        if (wave_any(inner)) {
+          double dV1 = 0.0, dV2 = 0.0;
+          // backward pass (with regularisation restarts)
+          while (true) {
+            bool fail;
+            ALTRO_STAMP(long long ts = stamp();)
+            if (wave_any(rs->rho != 0.0)) backward<true>(dV1, dV2, fail);
+            else backward<false>(dV1, dV2, fail);
+            ALTRO_STAMP(t_bw += stamp() - ts;)
+            if (inner) rs->nbw += 1;
+            fail = row_any(fail, lane) && inner;
+            double rho = rs->rho, drho = rs->drho;
+            if (fail) {
+              if (rho >= o.bp_reg_max) {
+                rs->status = ALTRO_NO_PROGRESS;
+                inner = false;
+                inner_end = true;
+              } else {
+                reg_update(rho, drho, o, true);
+              }
+            }
+            const bool again_bp = wave_any(fail && inner);
+            if (!again_bp && !fail && inner) reg_update(rho, drho, o, false);
+            rs->rho = rho;
+            rs->drho = drho;
+            __builtin_amdgcn_wave_barrier();
+            if (!again_bp) break;
+          }
+          // forward pass: line search on alpha (forwardpass!).  Trial 0 (alpha = 1) is
+          // the closed-loop rollout; later trials are evaluated by interpolation, NA per sweep.
+          const double J_prev = rs->J_prev;
+          double alpha = 1.0, zr = -1.0, Jn = __builtin_inf(), cm_n = rs->cmax;
+          int ls = 0, ntr = 0;
+          bool searching = inner, accepted = false, need_interp = false, ls_failed = false;
+          auto trial = [&](double a_t, double J_t, double cm_t, bool lim_t, bool unch_t) {
+            if (lim_t) {
+              ls++;
+              alpha = 0.5 * a_t;
+              return;
+            }
+            Jn = J_t;
+            const double expected = -a_t * (dV1 + a_t * dV2);
+            zr = (expected > 0.0) ? (J_prev - Jn) / expected : -1.0;
+            ls++;
+            const bool again = ((zr <= o.line_search_lower_bound) || (zr > o.line_search_upper_bound)) &&
+                               (Jn >= J_prev);
+            if (!again) {
+              searching = false;
+              accepted = true;
+              cm_n = cm_t;
+              alpha = a_t;
+            } else {
+              alpha = 0.5 * a_t;
+              // Exact early-out: if this trial reproduced the current trajectory bit for bit, every
+              // smaller alpha reproduces it too (round-to-nearest is monotone), J stays == J_prev,
+              // and the reference loop would spin to iterations_linesearch and fail.  Jump there.
+              if (unch_t) ls = o.iterations_linesearch + 1;
+            }
+          };
+          {
+            ALTRO_STAMP(long long ts = stamp();)
+            const RollOut rr = rollout<false>(true, false);
+            ALTRO_STAMP(t_rc += stamp() - ts;)
+            if (searching) {
+              rs->nro += 1;
+              trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged);
+            }
+          }
+          while (true) {
+            const bool failnow = searching && (ls > o.iterations_linesearch);
+            if (failnow) {
+              Jn = J_prev;
+              cm_n = rs->cmax;
+              alpha = 0.0;
+              ls_failed = true;
+              searching = false;
+            }
+            if (!wave_any(searching)) break;
+            ALTRO_STAMP(long long ts = stamp();)
+            Trials T;
+            trial_costs(alpha, T);
+            ALTRO_STAMP(t_ls += stamp() - ts;)
+            const double a0 = alpha;
+            sfor<0, NA>([&](auto t) {
+              constexpr int Tt = decltype(t)::value;
+              if (searching && ls <= o.iterations_linesearch) {
+                ntr++;
+                trial(a0 * (1.0 / (double)(1 << Tt)), T.J[Tt], T.cmax[Tt], T.limit[Tt], T.unchanged[Tt]);
+                if (accepted && !searching) need_interp = true;
+              }
+            });
+          }
+          if (wave_any(need_interp)) {
+            ALTRO_STAMP(long long ts = stamp();)
+            interpolate(alpha, need_interp);
+            ALTRO_STAMP(t_ls += stamp() - ts;)
+          }
+          // ---- bookkeeping of this iteration (record_iteration!, evaluate_convergence)
+          bool cand = false;
+          if (inner) {
+            rs->ntr += ntr;
+            if (ls_failed) {
+              double rho = rs->rho, drho = rs->drho;
+              reg_update(rho, drho, o, true);
+              rho += o.bp_reg_fp;
+              rs->rho = rho;
+              rs->drho = drho;
+            }
+            if (Jn > o.max_cost_value) {
+              rs->status = ALTRO_MAXIMUM_COST;
+              rs->J = Jn;
+              inner = false;
+              inner_end = true;
+            } else {
+              if (accepted) rs->cur = rs->cur ^ 1;  // copy_trajectories!
+              rs->cmax = cm_n;
+              const double dJ = fabs(Jn - J_prev);
+              rs->J_prev = Jn;
+              rs->J = Jn;
+              const int it_total = rs->iters;
+              if (it_total < ALTRO_TRACE_LEN && j == 0) {
+                P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + it_total] = Jn;
+                P.ctrace[(size_t)inst * ALTRO_TRACE_LEN + it_total] = cm_n;
+              }
+              rs->iters = it_total + 1;
+              rs->it += 1;
+              rs->dj_zero = (dJ == 0.0) ? rs->dj_zero + 1 : 0;
+              cand = dJ < rs->cost_tol;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // evaluate_convergence: (0 <= dJ < cost_tol) && grad < grad_tol -- the Todorov gradient
+          // is only evaluated for waves that hold a candidate
+          double grad = __builtin_inf();
+          if (wave_any(cand)) {
+            ALTRO_STAMP(long long ts = stamp();)
+            grad = todorov();
+            ALTRO_STAMP(t_td += stamp() - ts;)
+          }
+          if (inner) {
+            if (cand && grad < rs->grad_tol) {
+              inner_end = true;
+            } else if (rs->iters >= o.iterations) {
+              rs->status = ALTRO_MAX_ITERATIONS;
+              inner_end = true;
+            } else if (rs->dj_zero > o.dJ_counter_limit) {
+              rs->status = ALTRO_NO_PROGRESS;
+              inner_end = true;
+            } else if (rs->it >= o.iterations_inner) {
+              inner_end = true;
+            }
+          }
+        }
+        // ---------------- D. AL outer update for rows whose inner loop has ended
+        if (inner_end) {
+          const int status = rs->status;
+          const double cmax = rs->cmax;
+          if (has_con) rs->iters_outer += 1;
+          bool finished = false;
+          if (!has_con) {
+            if (status == ALTRO_UNSOLVED) rs->status = ALTRO_SOLVE_SUCCEEDED;
+            rs->cmax = 0.0;
+            finished = true;
+          } else if (status > ALTRO_SOLVE_SUCCEEDED) {
+            finished = true;
+          } else if (cmax < o.constraint_tolerance || rs->mu >= o.penalty_max) {
+            finished = true;
+          } else if (rs->last) {
+            rs->status = ALTRO_MAX_ITERATIONS_OUTER;
+            finished = true;
+          } else {
+            upd = true;
+          }
+          if (finished) {
+            if (has_con && rs->status <= ALTRO_SOLVE_SUCCEEDED && rs->cmax < o.constraint_tolerance)
+              rs->status = ALTRO_SOLVE_SUCCEEDED;
+            rs->nsolve += 1;
+            rs->nit += rs->iters;
+            rs->nok += (rs->status == ALTRO_SOLVE_SUCCEEDED) ? 1 : 0;
+            rs->step += 1;
+            rs->phase = PH_STEP_BEGIN;
+          } else {
+            rs->outer += 1;
+            rs->phase = PH_OUTER_BEGIN;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (wave_any(upd)) {
+        ALTRO_STAMP(long long ts = stamp();)
+        dual_update(upd);
+        ALTRO_STAMP(t_du += stamp() - ts;)
+        if (upd) rs->mu = fmin(fmax(phi * rs->mu, 0.0), o.penalty_max);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 
   __device__ void finish() {
-    stg(P.x0, rowoff, x0);
     if (j == 0) {
-      P.iters[inst] = iters;
-      P.iters_outer[inst] = iters_outer;
-      P.status[inst] = status;
-      P.cost[inst] = J;
-      P.cmax[inst] = cmax;
-      P.mu[inst] = mu;
-      P.cur[inst] = cur;
-      P.n_backward[inst] += nbw;
-      P.n_rollout[inst] += nro;
-      P.n_trials[inst] += ntr;
-      P.n_solves[inst] += nsolve;
-      P.n_iters[inst] += nit;
-      P.n_ok[inst] += nok;
+      P.iters[inst] = rs->iters;
+      P.iters_outer[inst] = rs->iters_outer;
+      P.status[inst] = rs->status;
+      P.cost[inst] = rs->J;
+      P.cmax[inst] = rs->cmax;
+      P.mu[inst] = rs->mu;
+      P.cur[inst] = rs->cur;
+      P.n_backward[inst] += rs->nbw;
+      P.n_rollout[inst] += rs->nro;
+      P.n_trials[inst] += rs->ntr;
+      P.n_solves[inst] += rs->nsolve;
+      P.n_iters[inst] += rs->nit;
+      P.n_ok[inst] += rs->nok;
     }
   }
 };
@@ -1003,19 +1109,11 @@ struct Solver {
 // reference window <- step+1; shift_fill primal and dual; solve.
 template <int NX, int NU>
 __global__ void __launch_bounds__(64, ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
-  __shared__ double sm[IPW * LW * (LW + 1)];
+  __shared__ double tiles[IPW * LW * (LW + 1)];
+  __shared__ RowState rows[IPW];
   const long long t0 = __builtin_amdgcn_s_memtime();
-  Solver<NX, NU> s(p);
-  const bool mpc = p.nsteps > 0;
-  const int n = mpc ? p.nsteps : 1;
-  for (int i = 0; i < n; ++i) {
-    if (mpc) {
-      const int step = p.first_step + i;
-      s.plant_step(step);
-      s.kref = step + 1;
-    }
-    s.solve(sm, mpc);
-  }
+  Solver<NX, NU> s(p, rows, tiles);
+  s.run(p.nsteps > 0, p.first_step, p.nsteps);
   s.finish();
   const long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) {
