@@ -133,7 +133,7 @@ def main():
 
     B, K, W = a.batch, a.steps, a.warmup
     pb = altro.problems.gen_random_linear_batch(B, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=K + W, seed=1,
-                                                first_instance=rank * B)
+                                                first_instance=altro.parallel.shard_first_instance(rank, B))
     mp = altro.mpc.BatchMPC(pb, device=local_rank)
     mp.initial_solve()
     for i in range(W):
@@ -168,11 +168,12 @@ def main():
     assert int(nsol.sum()) == B * K, (int(nsol.sum()), B * K)
     ok = int(nok.sum())
 
-    # final gather of the first controls (what an MPC consumer reads each tick)
-    U1 = torch.from_numpy(altro.controls(mp.solver)[:, 0].copy()).cuda()
+    # final gather of the first controls + status (what an MPC consumer reads each tick): the only
+    # collective of the run, after the timed region
+    U1 = altro.controls(mp.solver)[:, 0].copy()
+    allU, allS = altro.parallel.gather_results(U1, st.status, device="cuda")
+    assert allU.shape == (world * B, N_CTRL)
     if world > 1:
-        allU = torch.empty((world,) + tuple(U1.shape), dtype=U1.dtype, device="cuda")
-        dist.all_gather_into_tensor(allU, U1)
         oks = torch.tensor([ok], device="cuda")
         dist.all_reduce(oks)
         ok = int(oks.item())
