@@ -36,7 +36,7 @@ struct altro_handle {
   // problem data (device)
   double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
-  double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lhi = nullptr, *Llo = nullptr, *mu = nullptr,
+  double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lb = nullptr, *mu = nullptr,
          *KD = nullptr;
   double *noise = nullptr;
   int* cur = nullptr;
@@ -48,6 +48,9 @@ struct altro_handle {
   int kref = 0;  // current reference window start
   int noise_steps = 0;
   int box_k0 = 0, box_k1 = -1, box_id = -1;
+  int* bslot = nullptr;  // device [16]
+  int bslot_h[LW];       // host copy: slot of z element j among the bounded ones, -1 if none
+  int nbp = 1;           // slots per side of the compact dual rows
   int ncon = 0;
   bool have_dyn = false, have_cost = false, have_ref = false;
   bool dyn_per_instance = false;
@@ -181,36 +184,34 @@ __global__ void k_unpack_x0(double* __restrict__ x0, const double* __restrict__ 
   if (j < n) x0[(size_t)inst * n + j] = src[t];
 }
 
-// box duals: host [B][nk][2][nz]  <->  Lhi/Llo [N][Bp][16]
-__global__ void k_duals(double* __restrict__ host, double* __restrict__ Lhi, double* __restrict__ Llo, int B, int Bp,
-                        int nz, int k0, int k1, int to_host) {
+// box duals: host [B][nk][2][nz] (dense, zero for unbounded elements)  <->  Lb [N+1][Bp][2][nbp]
+__global__ void k_duals(double* __restrict__ host, double* __restrict__ Lb, const int* __restrict__ bslot, int nbp,
+                        int B, int Bp, int nz, int k0, int k1, int to_host) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
+  if (j >= nz) return;
   const int b = inst < B ? inst : B - 1;
   const int nk = k1 - k0 + 1;
+  const int sl = bslot[j];
   for (int k = k0; k <= k1; ++k) {
-    const size_t di = ((size_t)k * Bp + inst) * LW + j;
-    if (j < nz) {
-      const size_t hi = (((size_t)b * nk + (k - k0)) * 2 + 0) * nz + j;
-      const size_t lo = (((size_t)b * nk + (k - k0)) * 2 + 1) * nz + j;
-      if (to_host) {
-        if (inst < B) { host[hi] = Lhi[di]; host[lo] = Llo[di]; }
-      } else {
-        Lhi[di] = host[hi];
-        Llo[di] = host[lo];
-      }
-    } else if (!to_host) {
-      Lhi[di] = 0.0;
-      Llo[di] = 0.0;
+    const size_t hi = (((size_t)b * nk + (k - k0)) * 2 + 0) * nz + j;
+    const size_t lo = (((size_t)b * nk + (k - k0)) * 2 + 1) * nz + j;
+    const size_t dh = (((size_t)k * Bp + inst) * 2 + 0) * nbp + (sl >= 0 ? sl : 0);
+    const size_t dl = (((size_t)k * Bp + inst) * 2 + 1) * nbp + (sl >= 0 ? sl : 0);
+    if (to_host) {
+      if (inst < B) { host[hi] = sl >= 0 ? Lb[dh] : 0.0; host[lo] = sl >= 0 ? Lb[dl] : 0.0; }
+    } else if (sl >= 0) {
+      Lb[dh] = host[hi];
+      Lb[dl] = host[lo];
     }
   }
 }
 
 // RD.shift_fill!(Z) on the current plane and Altro.shift_fill!(conSet) on the box duals
 // (random_linear_problem.jl:136,139): entry k <- entry k+1, last entry kept.
-__global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, size_t plane, double* __restrict__ Lhi,
-                        double* __restrict__ Llo, int Bp, int N, int n, int m, int k0, int k1, int primal, int dual) {
+__global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, size_t plane, double* __restrict__ Lb,
+                        int nbp, int Bp, int N, int n, int m, int k0, int k1, int primal, int dual) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
@@ -222,10 +223,11 @@ __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, si
     if (j < n + m)
       for (int k = 0; k < kend; ++k) z[(size_t)k * ks] = z[(size_t)(k + 1) * ks];
   }
-  if (dual && k1 >= k0) {
-    for (int k = k0; k < k1; ++k) {
-      Lhi[(size_t)k * ks + off] = Lhi[(size_t)(k + 1) * ks + off];
-      Llo[(size_t)k * ks + off] = Llo[(size_t)(k + 1) * ks + off];
+  if (dual && k1 >= k0) {  // the 16 threads of the instance share the 2*nbp elements of its compact rows
+    const size_t ls = (size_t)Bp * 2 * nbp;
+    for (int e = j; e < 2 * nbp; e += LW) {
+      double* l = Lb + (size_t)inst * 2 * nbp + e;
+      for (int k = k0; k < k1; ++k) l[(size_t)k * ls] = l[(size_t)(k + 1) * ls];
     }
   }
 }
@@ -252,7 +254,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lhi = h->Lhi; p.Llo = h->Llo; p.mu = h->mu; p.KD = h->KD;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
@@ -368,8 +370,11 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMalloc(&h->x0, row * sizeof(double)));
   // + one trash row at the end of each (stores of rows that sit out a phase land there)
   CCHK(hipMalloc(&h->Z, (2 * N + 1) * row * sizeof(double)));
-  CCHK(hipMalloc(&h->Lhi, (N + 1) * row * sizeof(double)));
-  CCHK(hipMalloc(&h->Llo, (N + 1) * row * sizeof(double)));
+  for (int j = 0; j < LW; ++j) h->bslot_h[j] = -1;
+  h->nbp = 1;
+  CCHK(hipMalloc(&h->Lb, (N + 1) * Bp * 2 * h->nbp * sizeof(double)));
+  CCHK(hipMalloc(&h->bslot, LW * sizeof(int)));
+  CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
   CCHK(hipMalloc(&h->KD, (N - 1) * Bp * m * LW * sizeof(double)));
   CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
@@ -395,8 +400,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Lhi, 0, (N + 1) * row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Llo, 0, (N + 1) * row * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->Lb, 0, (N + 1) * Bp * 2 * h->nbp * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->KD, 0, (N - 1) * Bp * m * LW * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
   CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));
@@ -426,7 +430,7 @@ int32_t altro_batch_destroy(altro_handle* h) {
   if (!h) return ALTRO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lhi, h->Llo,
+  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot,
                   h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
                   h->ctrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
   for (void* p : ptrs)
@@ -492,6 +496,19 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
   for (int j = 0; j < nz; ++j) { lo[j] = zmin[j]; hi[j] = zmax[j]; }
   HIPCHK(h, hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // compact dual rows: one slot per element with at least one finite bound
+  int nb = 0;
+  for (int j = 0; j < LW; ++j) h->bslot_h[j] = (j < nz && (std::isfinite(lo[j]) || std::isfinite(hi[j]))) ? nb++ : -1;
+  h->nbp = nb > 0 ? nb : 1;
+  HIPCHK(h, hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(h->Lb));
+  h->Lb = nullptr;
+  {
+    const size_t lbytes = (size_t)(h->d.N + 1) * h->Bp * 2 * h->nbp * sizeof(double);
+    HIPCHK(h, hipMalloc(&h->Lb, lbytes));
+    HIPCHK(h, hipMemsetAsync(h->Lb, 0, lbytes, h->stream));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->box_k0 = k_first;
   h->box_k1 = k_last;
@@ -584,8 +601,8 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t plane = (size_t)h->d.N * h->Bp * LW;
-  hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lhi,
-                     h->Llo, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0);
+  hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lb,
+                     h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0);
   HIPCHK(h, hipGetLastError());
   return ALTRO_OK;
 }
@@ -674,7 +691,7 @@ static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_ho
   int rc = ensure_stage(h, cnt * sizeof(double));
   if (rc) return rc;
   if (!to_host && (rc = upload(h, lambda, cnt))) return rc;
-  hipLaunchKernelGGL(k_duals, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->Lhi, h->Llo,
+  hipLaunchKernelGGL(k_duals, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->Lb, h->bslot, h->nbp,
                      h->d.batch, h->Bp, nz, h->box_k0, h->box_k1, to_host);
   HIPCHK(h, hipGetLastError());
   if (to_host) HIPCHK(h, hipMemcpyAsync(lambda, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -86,8 +86,10 @@ struct SolveParams {
   const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
   double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
   int* cur;              // [Bp] which plane of Z is current
-  double* Lhi;           // [N+1][Bp][16] duals of z - zmax <= 0  (knot N = trash row)
-  double* Llo;           // [N+1][Bp][16] duals of zmin - z <= 0
+  double* Lb;            // [N+1][Bp][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
+                         // z - zmax <= 0, side 1 = duals of zmin - z <= 0  (knot N = trash row)
+  const int* bslot;      // [16] slot of lane j's element among the bounded ones, -1 if unbounded
+  int nbp;               // slots per side (>= 1)
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
   double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
   int* iters;
@@ -212,6 +214,8 @@ struct Solver {
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
   unsigned kstride;  // Bp*16                 that every array stays below 2^32 bytes)
+  unsigned lslot;    // this lane's slot in the compact dual rows (0 for unbounded lanes: dummy)
+  bool bounded;
   ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls;)
 
   struct LaneConst {
@@ -229,6 +233,11 @@ struct Solver {
     is_u = (j >= NX) && (j < NZ);
     rowoff = (unsigned)inst * LW + j;
     kstride = (unsigned)P.Bp * LW;
+    {
+      const int sl = P.bslot[j];
+      bounded = sl >= 0;
+      lslot = bounded ? (unsigned)sl : 0u;
+    }
     ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
   }
 
@@ -247,7 +256,11 @@ struct Solver {
   // plane c of Z as an element offset (per instance: cur differs between rows)
   __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * kstride; }
   __device__ __forceinline__ unsigned trash_z() const { return 2u * (unsigned)P.N * kstride + rowoff; }
-  __device__ __forceinline__ unsigned trash_l() const { return (unsigned)P.N * kstride + rowoff; }
+  // compact dual rows: element offset of (knot k, side, this lane's slot); knot N is the trash row
+  __device__ __forceinline__ unsigned lb_at(int k, int side) const {
+    return (((unsigned)k * P.Bp + inst) * 2u + (unsigned)side) * (unsigned)P.nbp + lslot;
+  }
+  __device__ __forceinline__ unsigned trash_l(int side) const { return lb_at(P.N, side); }
   __device__ __forceinline__ bool box_at(int k) const { return k >= P.box_k0 && k <= P.box_k1; }
   __device__ __forceinline__ unsigned kd_at(int k, int row) const {
     return (((unsigned)k * P.Bp + inst) * NU + row) * LW + j;
@@ -328,9 +341,9 @@ struct Solver {
       const int kl = imax(imin(k + 1, k1), 0);
       in.z = ldg(P.Z, zs + at(shu ? ku : k));
       in.zr = ldg(P.Zref, at(kref + k));
-      const unsigned li = at(shl ? kl : k);
-      in.lhi = ldg(P.Lhi, li);
-      in.llo = ldg(P.Llo, li);
+      const int kk = shl ? kl : k;
+      in.lhi = ldg(P.Lb, lb_at(kk, 0));
+      in.llo = ldg(P.Lb, lb_at(kk, 1));
       if constexpr (!OPEN) {
         sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
       }
@@ -343,9 +356,9 @@ struct Solver {
       if constexpr (OPEN) {
         zb = is_x ? xb : in.z;
         stg(P.Z, take ? (zd + at(k)) : trash_z(), zb);
-        const unsigned li = wr_l ? at(k) : trash_l();
-        stg(P.Lhi, li, lhi);
-        stg(P.Llo, li, llo);
+        const bool wl = wr_l & bounded;
+        stg(P.Lb, wl ? lb_at(k, 0) : trash_l(0), lhi);
+        stg(P.Lb, wl ? lb_at(k, 1) : trash_l(1), llo);
       } else {
         // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
         const double dx = is_x ? (xb - in.z) : 0.0;
@@ -381,7 +394,7 @@ struct Solver {
     // terminal-knot operands (independent of the pipeline)
     const int kt = N - 1;
     const double t_zr = ldg(P.Zref, at(kref + kt));
-    const double t_lhi = ldg(P.Lhi, at(kt)), t_llo = ldg(P.Llo, at(kt));
+    const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
     double t_z = 0.0;
     if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
 
@@ -498,8 +511,8 @@ struct Solver {
         z[Q] = ldg(P.Z, zs + at(k));
         zz1[Q] = ldg(P.Z, z1 + at(k));
         zr[Q] = ldg(P.Zref, at(kref + k));
-        lhi[Q] = ldg(P.Lhi, at(k));
-        llo[Q] = ldg(P.Llo, at(k));
+        lhi[Q] = ldg(P.Lb, lb_at(k, 0));
+        llo[Q] = ldg(P.Lb, lb_at(k, 1));
       });
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
@@ -601,7 +614,7 @@ struct Solver {
       const int k = N - 1;
       const double z = ldg(P.Z, zs + at(k));
       const double zr = ldg(P.Zref, at(kref + k));
-      const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
+      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       double qz = lc.wf * (z - zr), hz = lc.wf;
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz);
       sfor<0, NX>([&](auto c) {
@@ -616,12 +629,12 @@ struct Solver {
     double* my = sm;
     // operands of the knot about to be processed (loaded one knot ahead)
     double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
-    double lhi = ldg(P.Lhi, at(N - 2)), llo = ldg(P.Llo, at(N - 2));
+    double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + at(km));
       const double zrn = ldg(P.Zref, at(kref + km));
-      const double lhin = ldg(P.Lhi, at(km)), llon = ldg(P.Llo, at(km));
+      const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
       double qz = lc.wd * (z - zr), hz = lc.wd;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
@@ -757,11 +770,11 @@ struct Solver {
     for (int k = P.box_k0; k <= P.box_k1; ++k) {
       const bool on = (k < P.N - 1) ? (is_x | is_u) : is_x;
       const double z = ldg(P.Z, zs + at(k));
-      const double lhi = ldg(P.Lhi, at(k)), llo = ldg(P.Llo, at(k));
+      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       const double nhi = fmin(fmax(lhi + mu * (z - lc.zmax), 0.0), dmax);
       const double nlo = fmin(fmax(llo + mu * (lc.zmin - z), 0.0), dmax);
-      stg(P.Lhi, (upd & on & lc.has_hi) ? at(k) : trash_l(), nhi);
-      stg(P.Llo, (upd & on & lc.has_lo) ? at(k) : trash_l(), nlo);
+      stg(P.Lb, (upd & on & lc.has_hi) ? lb_at(k, 0) : trash_l(0), nhi);
+      stg(P.Lb, (upd & on & lc.has_lo) ? lb_at(k, 1) : trash_l(1), nlo);
     }
   }
 
@@ -823,8 +836,8 @@ struct Solver {
           if (mpc && wave_any(go)) plant_step(go, first_step + stp);
           if (o.reset_duals && wave_any(go)) {  // initialize!: lambda <- 0
             for (int k = P.box_k0; k <= P.box_k1; ++k) {
-              stg(P.Lhi, go ? at(k) : trash_l(), 0.0);
-              stg(P.Llo, go ? at(k) : trash_l(), 0.0);
+              stg(P.Lb, (go & bounded) ? lb_at(k, 0) : trash_l(0), 0.0);
+              stg(P.Lb, (go & bounded) ? lb_at(k, 1) : trash_l(1), 0.0);
             }
           }
           if (begin) {

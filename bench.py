@@ -45,6 +45,20 @@ def bytes_solve(n, m, N, p):
                 + (N * n + (N - 1) * m) + 2 * (N - 1) * p + 12)
 
 
+def measured_traffic(batch, steps, spl, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command; FETCH_SIZE doubled per MI355X_MICROARCH.md and tools/probes/fetch_calib.hip).
+    Only returned when the committed measurement is for exactly this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("batch") == batch and t.get("steps") == steps and t.get("steps_per_launch") == spl and world == 1:
+        return t["hbm_bytes_per_launch"]
+    return None
+
+
 def _cpu_worker(args):
     """Run whole MPC loops of the oracle for ~budget seconds on one core."""
     first, count, steps, budget = args
@@ -208,7 +222,7 @@ def main():
                                   "(run_random_linear.jl:41-49)",
                        "parallelism": "instances sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic(B, K, spl, world),
                          "kernel": "altro::solve_kernel<12,4>", "avg_launch_ms": avg_ms, "launches": int(len(ms)),
                          "note": "FP64 VALU (v_fmac_f64_dpp) path; MI355X FP64 vector peak = FP64 matrix peak",
                          "hbm_algorithmic_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,

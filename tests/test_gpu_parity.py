@@ -205,6 +205,7 @@ def test_shift_fill_and_accessors_roundtrip():
     altro.initial_controls(sv, U)
     assert np.array_equal(altro.controls(sv), U)
     lam = rng.random((B, 8, 2, 9))
+    lam[..., :6] = 0.0   # only bounded elements (the controls) carry duals, as in BoundConstraint
     altro.set_duals(sv, lam)
     assert np.array_equal(altro.get_duals(sv), lam)
     altro.shift_fill(sv, True, True)
