@@ -7,7 +7,8 @@ restates the reference's problem generators and MPC harness (problems.py, mpc.py
 """
 from . import _lib, mpc, parallel, problems  # noqa: F401
 from ._lib import SOLVE_SUCCEEDED, STATUS_NAMES  # noqa: F401
-from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, LinearModel, Problem,  # noqa: F401
+from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, GoalConstraint, LinearConstraint,
+                  LinearModel, NormConstraint, Problem,  # noqa: F401
                   SolverOptions, TrackingObjective, controls, cost, get_duals, initial_controls,
                   iterations, max_violation, set_duals, set_initial_state, set_options, shift_fill,
                   solve, solve_counters, states, stats, status, timing_get, timing_reset, update_trajectory,

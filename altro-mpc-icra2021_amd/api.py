@@ -100,6 +100,30 @@ class BoundConstraint:
 
 
 @dataclass
+class LinearConstraint:
+    """A z + b {= 0 | <= 0}; A is (p, n+m) on z = [x; u].  Mirrors TO.LinearConstraint /
+    GoalConstraint(xf) (A = [I 0], b = -xf) / LinearizedFrictionConstraint."""
+    A: np.ndarray
+    b: np.ndarray
+    equality: bool = False
+
+
+@dataclass
+class NormConstraint:
+    """Second-order cone: ||(A z + b)[0:p-1]|| <= (A z + b)[p-1].  Mirrors NormConstraint(n, m, val,
+    SecondOrderCone(), :control) (rocket_landing_problem.jl:123) and NormConstraint2 ([A y; c'y],
+    new_constraints.jl:72-120) with their rows written on z."""
+    A: np.ndarray
+    b: np.ndarray
+
+
+def GoalConstraint(xf, n, m):
+    """GoalConstraint(xf) (rocket_landing_problem.jl:96): x_N = xf, added at knot N."""
+    xf = np.asarray(xf, dtype=np.float64)
+    return LinearConstraint(np.hstack([np.eye(n), np.zeros((n, m))]), -xf, equality=True)
+
+
+@dataclass
 class ConstraintList:
     n: int
     m: int
@@ -159,6 +183,16 @@ class ALTROSolver:
                 cid = C.c_int32(-1)
                 self._chk(L.altro_batch_add_constraint(h, _lib.CON_BOX, _lib.SENSE_INEQ, first - 1, last - 1, 0,
                                                        None, None, _p(_c(zmin)), _p(_c(zmax)), 0, C.byref(cid)))
+                self.con_ids.append(cid.value)
+            elif isinstance(con, (LinearConstraint, NormConstraint)):
+                A, b = _c(con.A), _c(con.b)
+                assert A.shape == (b.shape[0], n + m)
+                soc = isinstance(con, NormConstraint)
+                kind = _lib.CON_SOC if soc else _lib.CON_LINEAR
+                sense = _lib.SENSE_EQ if (not soc and con.equality) else _lib.SENSE_INEQ
+                cid = C.c_int32(-1)
+                self._chk(L.altro_batch_add_constraint(h, kind, sense, first - 1, last - 1, A.shape[0],
+                                                       _p(A), _p(b), None, None, 0, C.byref(cid)))
                 self.con_ids.append(cid.value)
             else:
                 raise AltroError(_lib.ERR_UNSUPPORTED, f"constraint type {type(con).__name__} is not built yet")
@@ -229,9 +263,12 @@ def controls(solver):
 
 
 def get_duals(solver, con=0):
-    first, last = solver.prob.constraints.items[con][1:]
+    c, first, last = solver.prob.constraints.items[con]
     nk = last - first + 1
-    lam = np.empty((solver.B, nk, 2, solver.n + solver.m))
+    if isinstance(c, BoundConstraint):
+        lam = np.empty((solver.B, nk, 2, solver.n + solver.m))
+    else:
+        lam = np.empty((solver.B, nk, np.asarray(c.b).shape[0]))
     solver._chk(solver._L.altro_batch_get_duals(solver.h, solver.con_ids[con], _p(lam)))
     return lam
 

@@ -48,6 +48,21 @@ struct altro_handle {
   int kref = 0;  // current reference window start
   int noise_steps = 0;
   int box_k0 = 0, box_k1 = -1, box_id = -1;
+  // generic affine constraints packed into 4 quads of 4 constraint rows (see solve_dpp16.h)
+  double *Acon = nullptr, *bcon = nullptr, *Lc = nullptr;
+  int* cmeta = nullptr;
+  double Acon_h[LW * LW];
+  double bcon_h[LW];
+  int cmeta_h[LW * 4];
+  int ncrows = 0;       // 16 once any generic constraint exists (kernel flag)
+  bool con_dirty = false, con_locked = false;  // packing is redone until the first solve
+  struct ConBlock {
+    int id, kind, sense, k0, k1, p;
+    std::vector<double> A, b;  // A row-major p x nz
+    int lanes[LW];
+  };
+  std::vector<ConBlock> cons;
+  int* lanebuf = nullptr;  // device scratch [16] for dual transfers
   int* bslot = nullptr;  // device [16]
   int bslot_h[LW];       // host copy: slot of z element j among the bounded ones, -1 if none
   int nbp = 1;           // slots per side of the compact dual rows
@@ -211,7 +226,8 @@ __global__ void k_duals(double* __restrict__ host, double* __restrict__ Lb, cons
 // RD.shift_fill!(Z) on the current plane and Altro.shift_fill!(conSet) on the box duals
 // (random_linear_problem.jl:136,139): entry k <- entry k+1, last entry kept.
 __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, size_t plane, double* __restrict__ Lb,
-                        int nbp, int Bp, int N, int n, int m, int k0, int k1, int primal, int dual) {
+                        int nbp, int Bp, int N, int n, int m, int k0, int k1, int primal, int dual,
+                        double* __restrict__ Lc, const int* __restrict__ cmeta, int ncrows) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
@@ -229,6 +245,25 @@ __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, si
       double* l = Lb + (size_t)inst * 2 * nbp + e;
       for (int k = k0; k < k1; ++k) l[(size_t)k * ls] = l[(size_t)(k + 1) * ls];
     }
+  }
+  if (dual && j < ncrows) {  // generic constraint row j: its own knot range
+    const int c0 = cmeta[4 * j + 1], c1 = cmeta[4 * j + 2];
+    for (int k = c0; k < c1; ++k) Lc[(size_t)k * ks + off] = Lc[(size_t)(k + 1) * ks + off];
+  }
+}
+
+// duals of one generic constraint block: host [B][nk][p]  <->  Lc [N+1][Bp][16], rows on lanes lane0..lane0+p-1
+__global__ void k_cduals(double* __restrict__ host, double* __restrict__ Lc, int B, int Bp, const int* __restrict__ lanes,
+                         int p, int k0, int k1, int to_host) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * p) return;
+  const int inst = t / p, r = t % p;
+  const int nk = k1 - k0 + 1;
+  for (int k = k0; k <= k1; ++k) {
+    const size_t hi = ((size_t)inst * nk + (k - k0)) * p + r;
+    const size_t di = ((size_t)k * Bp + inst) * LW + lanes[r];
+    if (to_host) host[hi] = Lc[di];
+    else Lc[di] = host[hi];
   }
 }
 
@@ -254,7 +289,8 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.KD = h->KD;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu;
+  p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
@@ -262,11 +298,18 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.o = h->o;
   const dim3 grid(h->Bp / IPW), block(64);
   const int n = h->d.n, m = h->d.m;
-  if (n == 12 && m == 4) hipLaunchKernelGGL((altro::solve_kernel<12, 4>), grid, block, 0, h->stream, p);
-  else if (n == 6 && m == 3) hipLaunchKernelGGL((altro::solve_kernel<6, 3>), grid, block, 0, h->stream, p);
-  else if (n == 6 && m == 6) hipLaunchKernelGGL((altro::solve_kernel<6, 6>), grid, block, 0, h->stream, p);
-  else if (n == 8 && m == 4) hipLaunchKernelGGL((altro::solve_kernel<8, 4>), grid, block, 0, h->stream, p);
+  const bool cones = h->ncrows > 0;
+#define ALTRO_LAUNCH(NX_, NU_)                                                                            \
+  do {                                                                                                    \
+    if (cones) hipLaunchKernelGGL((altro::solve_kernel<NX_, NU_, true>), grid, block, 0, h->stream, p);  \
+    else hipLaunchKernelGGL((altro::solve_kernel<NX_, NU_, false>), grid, block, 0, h->stream, p);       \
+  } while (0)
+  if (n == 12 && m == 4) ALTRO_LAUNCH(12, 4);
+  else if (n == 6 && m == 3) ALTRO_LAUNCH(6, 3);
+  else if (n == 6 && m == 6) ALTRO_LAUNCH(6, 6);
+  else if (n == 8 && m == 4) ALTRO_LAUNCH(8, 4);
   else FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
+#undef ALTRO_LAUNCH
   HIPCHK(h, hipGetLastError());
   return ALTRO_OK;
 }
@@ -374,6 +417,18 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   h->nbp = 1;
   CCHK(hipMalloc(&h->Lb, (N + 1) * Bp * 2 * h->nbp * sizeof(double)));
   CCHK(hipMalloc(&h->bslot, LW * sizeof(int)));
+  CCHK(hipMalloc(&h->Acon, LW * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->bcon, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->cmeta, LW * 4 * sizeof(int)));
+  CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
+  CCHK(hipMalloc(&h->Lc, (N + 1) * row * sizeof(double)));
+  std::memset(h->Acon_h, 0, sizeof(h->Acon_h));
+  std::memset(h->bcon_h, 0, sizeof(h->bcon_h));
+  for (int r = 0; r < LW; ++r) { h->cmeta_h[4 * r] = 0; h->cmeta_h[4 * r + 1] = 0; h->cmeta_h[4 * r + 2] = -1; h->cmeta_h[4 * r + 3] = 0; }
+  CCHK(hipMemcpyAsync(h->Acon, h->Acon_h, sizeof(h->Acon_h), hipMemcpyHostToDevice, h->stream));
+  CCHK(hipMemcpyAsync(h->bcon, h->bcon_h, sizeof(h->bcon_h), hipMemcpyHostToDevice, h->stream));
+  CCHK(hipMemcpyAsync(h->cmeta, h->cmeta_h, sizeof(h->cmeta_h), hipMemcpyHostToDevice, h->stream));
+  CCHK(hipMemsetAsync(h->Lc, 0, (N + 1) * row * sizeof(double), h->stream));
   CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
   CCHK(hipMalloc(&h->KD, (N - 1) * Bp * m * LW * sizeof(double)));
@@ -430,7 +485,7 @@ int32_t altro_batch_destroy(altro_handle* h) {
   if (!h) return ALTRO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot,
+  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot, h->Acon, h->bcon, h->cmeta, h->Lc, h->lanebuf,
                   h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
                   h->ctrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
   for (void* p : ptrs)
@@ -481,17 +536,89 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const d
   return ALTRO_OK;
 }
 
+// Pack the recorded LINEAR / SOC constraints onto the 16 constraint-row lanes: every cone takes
+// the first p lanes of an aligned quad, linear rows fill whatever lanes remain (also the spare
+// lanes of a cone's quad).  Redone whenever a constraint is added before the first solve.
+static int pack_constraints(altro_handle* h) {
+  if (!h->con_dirty) return ALTRO_OK;
+  const int nz = h->d.n + h->d.m;
+  std::memset(h->Acon_h, 0, sizeof(h->Acon_h));
+  std::memset(h->bcon_h, 0, sizeof(h->bcon_h));
+  bool used[LW] = {false};
+  bool quad_soc[4] = {false, false, false, false};
+  for (int r = 0; r < LW; ++r) { h->cmeta_h[4 * r] = 0; h->cmeta_h[4 * r + 1] = 0; h->cmeta_h[4 * r + 2] = -1; h->cmeta_h[4 * r + 3] = 0; }
+  auto place = [&](altro_handle::ConBlock& cb, int r, int lane, int type, int pdim) {
+    cb.lanes[r] = lane;
+    used[lane] = true;
+    for (int jj = 0; jj < nz; ++jj) h->Acon_h[lane * LW + jj] = cb.A[(size_t)r * nz + jj];
+    h->bcon_h[lane] = cb.b[r];
+    h->cmeta_h[4 * lane + 0] = type;
+    h->cmeta_h[4 * lane + 1] = cb.k0;
+    h->cmeta_h[4 * lane + 2] = cb.k1;
+    h->cmeta_h[4 * lane + 3] = pdim;
+  };
+  for (auto& cb : h->cons) {
+    if (cb.kind != ALTRO_CON_SOC) continue;
+    int q = 0;
+    while (q < 4 && quad_soc[q]) ++q;
+    if (q == 4) FAIL(h, ALTRO_ERR_UNSUPPORTED, "more than 4 second-order cones per problem");
+    quad_soc[q] = true;
+    for (int r = 0; r < cb.p; ++r) place(cb, r, 4 * q + r, 3, cb.p);
+  }
+  for (auto& cb : h->cons) {
+    if (cb.kind != ALTRO_CON_LINEAR) continue;
+    int lane = 0;
+    for (int r = 0; r < cb.p; ++r) {
+      while (lane < LW && used[lane]) ++lane;
+      if (lane == LW) FAIL(h, ALTRO_ERR_UNSUPPORTED, "more than 16 constraint rows per knot");
+      place(cb, r, lane, cb.sense == ALTRO_SENSE_EQ ? 1 : 2, 0);
+    }
+  }
+  // a linear row inside a cone's quad must see that cone's dimension (it is excluded by pos >= p)
+  for (int q = 0; q < 4; ++q) {
+    int pdim = 0;
+    for (int i = 0; i < 4; ++i)
+      if (h->cmeta_h[4 * (4 * q + i)] == 3) pdim = h->cmeta_h[4 * (4 * q + i) + 3];
+    for (int i = 0; i < 4; ++i) h->cmeta_h[4 * (4 * q + i) + 3] = pdim;
+  }
+  h->ncrows = h->cons.empty() ? 0 : LW;
+  HIPCHK(h, hipMemcpyAsync(h->Acon, h->Acon_h, sizeof(h->Acon_h), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->bcon, h->bcon_h, sizeof(h->bcon_h), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->cmeta, h->cmeta_h, sizeof(h->cmeta_h), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->con_dirty = false;
+  return ALTRO_OK;
+}
+
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first, int32_t k_last,
                                    int32_t p, const double* A, const double* b, const double* zmin, const double* zmax,
                                    int32_t per_knot, int32_t* con_id) {
-  (void)sense; (void)p; (void)A; (void)b; (void)per_knot;
   if (!h) return ALTRO_ERR_INVALID_ARG;
   if (k_first < 0 || k_last >= h->d.N || k_last < k_first) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad knot range");
-  if (kind != ALTRO_CON_BOX) FAIL(h, ALTRO_ERR_UNSUPPORTED, "only BOX constraints are built in this round (LINEAR / SOC: next)");
-  if (h->box_id >= 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "one BOX constraint per problem");
-  if (!zmin || !zmax) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const int nz = h->d.n + h->d.m;
+  if (kind == ALTRO_CON_LINEAR || kind == ALTRO_CON_SOC) {
+    if (!A || !b || p < 1) return ALTRO_ERR_INVALID_ARG;
+    if (per_knot) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data is not built yet");
+    if (kind == ALTRO_CON_SOC && (p < 2 || p > 4)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "second-order cones of dimension 2..4 are built");
+    if (kind == ALTRO_CON_LINEAR && sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
+    if (h->con_locked) FAIL(h, ALTRO_ERR_STATE, "constraints must be added before the first solve");
+    altro_handle::ConBlock cb;
+    cb.id = h->ncon; cb.kind = kind; cb.sense = sense; cb.k0 = k_first; cb.k1 = k_last; cb.p = p;
+    cb.A.assign(A, A + (size_t)p * nz);
+    cb.b.assign(b, b + p);
+    for (int r = 0; r < LW; ++r) cb.lanes[r] = -1;
+    h->cons.push_back(cb);
+    h->con_dirty = true;
+    int rc = pack_constraints(h);
+    if (rc) { h->cons.pop_back(); h->con_dirty = true; pack_constraints(h); return rc; }
+    if (con_id) *con_id = h->ncon;
+    h->ncon++;
+    return ALTRO_OK;
+  }
+  if (kind != ALTRO_CON_BOX) return ALTRO_ERR_INVALID_ARG;
+  if (h->box_id >= 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "one BOX constraint per problem");
+  if (!zmin || !zmax) return ALTRO_ERR_INVALID_ARG;
   std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
   for (int j = 0; j < nz; ++j) { lo[j] = zmin[j]; hi[j] = zmax[j]; }
   HIPCHK(h, hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -520,7 +647,7 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
 int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A, const double* b) {
   (void)con_id; (void)A; (void)b;
   if (!h) return ALTRO_ERR_INVALID_ARG;
-  FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data (LINEAR / SOC) is not built in this round");
+  FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data is not built yet (constraint data is time-invariant)");
 }
 
 int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
@@ -602,7 +729,8 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
   HIPCHK(h, hipSetDevice(h->device));
   const size_t plane = (size_t)h->d.N * h->Bp * LW;
   hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lb,
-                     h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0);
+                     h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0, h->Lc,
+                     h->cmeta, h->ncrows);
   HIPCHK(h, hipGetLastError());
   return ALTRO_OK;
 }
@@ -617,6 +745,8 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = check_ready(h);
   if (rc) return rc;
+  if ((rc = pack_constraints(h))) return rc;
+  h->con_locked = true;
   const int last_kref = nsteps > 0 ? first_step + nsteps : h->kref;
   if (last_kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -683,8 +813,23 @@ int32_t altro_batch_get_controls(altro_handle* h, double* U) {
 }
 
 static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_host) {
-  if (con_id != h->box_id || h->box_id < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown constraint id");
   HIPCHK(h, hipSetDevice(h->device));
+  for (const auto& cb : h->cons) {
+    if (cb.id != con_id) continue;
+    const size_t nk = cb.k1 - cb.k0 + 1;
+    const size_t cnt = (size_t)h->d.batch * nk * cb.p;
+    int rc = ensure_stage(h, cnt * sizeof(double));
+    if (rc) return rc;
+    if (!to_host && (rc = upload(h, lambda, cnt))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->lanebuf, cb.lanes, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_cduals, grid_for((size_t)h->d.batch * cb.p), dim3(256), 0, h->stream, h->stage, h->Lc,
+                       h->d.batch, h->Bp, h->lanebuf, cb.p, cb.k0, cb.k1, to_host);
+    HIPCHK(h, hipGetLastError());
+    if (to_host) HIPCHK(h, hipMemcpyAsync(lambda, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  }
+  if (con_id != h->box_id || h->box_id < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown constraint id");
   const int nz = h->d.n + h->d.m;
   const size_t nk = h->box_k1 - h->box_k0 + 1;
   const size_t cnt = (size_t)h->d.batch * nk * 2 * nz;

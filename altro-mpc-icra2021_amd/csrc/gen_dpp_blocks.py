@@ -102,6 +102,13 @@ def gen(NX, NU):
         [(f"a{p}", f"acc[{p}]") for p in range(NP)],
         [("z", "z")] + [(f"g{j}", f"grow[{j}]") for j in range(NZ)]))
 
+    # ---- HC: h[i] += sum_r bcast_i(acol[r]) * y[r],  i < NZ, r < 16   (H += A' (M A), column per lane)
+    body = [fmac(f"h{i}", f"c{r}", f"y{r}", i) for r in range(16) for i in range(NZ)]
+    out.append(emit_block(
+        "HC", f"double (&h)[{NZ}], const double (&acol)[16], const double (&y)[16]", body,
+        [(f"h{i}", f"h[{i}]") for i in range(NZ)],
+        [(f"c{r}", f"acol[{r}]") for r in range(16)] + [(f"y{r}", f"y[{r}]") for r in range(16)]))
+
     out.append("};\n\n")
     return "".join(out)
 
@@ -113,6 +120,16 @@ def gen_common():
     s = "struct BlkCommon {\n"
     s += emit_block("ROWSUM", f"double (&acc)[{NP}], const double& v, const double& one", body,
                     [(f"a{p}", f"acc[{p}]") for p in range(NP)], [("v", "v"), ("one", "one")])
+    # ---- generic affine constraints: 16 constraint rows per knot, row r on lane r, 4 quads of 4
+    # RS16: acc_p += sum_{r in part p} bcast_r(v) * coef[r]      ((A' g)[lane] with coef = column of A)
+    body = [fmac(f"a{r % NP}", "v", f"c{r}", r) for r in range(16)]
+    s += emit_block("RS16", f"double (&acc)[{NP}], const double& v, const double (&coef)[16]", body,
+                    [(f"a{p}", f"acc[{p}]") for p in range(NP)], [("v", "v")] + [(f"c{r}", f"coef[{r}]") for r in range(16)])
+    # YM: y[r] += sum_q bcast_r(m[q]) * acol[4*(r/4)+q]          (Y = M A, block-diagonal 4x4 M, row r of M on lane r)
+    body = [fmac(f"y{r}", f"m{q}", f"c{4 * (r // 4) + q}", r) for q in range(4) for r in range(16)]
+    s += emit_block("YM", "double (&y)[16], const double (&m)[4], const double (&acol)[16]", body,
+                    [(f"y{r}", f"y[{r}]") for r in range(16)],
+                    [(f"m{q}", f"m[{q}]") for q in range(4)] + [(f"c{r}", f"acol[{r}]") for r in range(16)])
     s += "};\n\n"
     return s
 

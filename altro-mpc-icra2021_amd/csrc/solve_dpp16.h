@@ -91,6 +91,15 @@ struct SolveParams {
   const int* bslot;      // [16] slot of lane j's element among the bounded ones, -1 if unbounded
   int nbp;               // slots per side (>= 1)
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
+  // generic affine constraints (LINEAR eq/ineq, SOC): up to 16 constraint rows per knot, row r
+  // on lane r, organised in 4 quads of 4 lanes; a quad is one cone (SOC of dimension <= 4, or
+  // up to 4 independent equality / inequality rows).  Data is shared by all instances.
+  const double* Acon;    // [16][16] row-major: value_r = sum_j Acon[r][j] z_j + bcon[r]
+  const double* bcon;    // [16]
+  const int* cmeta;      // [16][4] per lane: type (0 none, 1 EQ, 2 INEQ, 3 SOC), k0, k1, p (dimension of the
+                         // cone this lane's quad holds; linear rows may use the quad's spare lanes)
+  double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
+  int ncrows;            // 0: no generic constraints
   double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
   int* iters;
   int* iters_outer;
@@ -193,6 +202,110 @@ __device__ __forceinline__ void reg_update(double& rho, double& drho, const altr
   }
 }
 
+// value of lane (lane & ~3) + Q of this lane's quad (4 consecutive lanes): two 32-bit DPP moves
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);  // quad_perm:[Q,Q,Q,Q]
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Per-lane metadata of the constraint row this lane owns
+struct ConMeta {
+  int type, k0, k1, p, pos;  // pos = lane & 3
+};
+enum { CT_NONE = 0, CT_EQ = 1, CT_INEQ = 2, CT_SOC = 3 };
+
+// Result of evaluating one constraint row (on its lane) at one knot
+struct ConeEval {
+  double cost;     // AL penalty contribution of this row
+  double viol;     // violation contribution (max-reduced over rows)
+  double g;        // d phi / d value_r
+  double m[4];     // row `pos` of the quad's 4x4 Hessian weight M (phi_vv), columns q = 0..3
+  double lam_new;  // dual update candidate
+};
+
+// AL terms of one constraint row (oracle con_cost / cost_expansion / dual update).
+//   EQ:   phi = lam v + 1/2 mu v^2
+//   INEQ: phi = lam v + 1/2 mu v^2 [v >= 0 or lam > 0]
+//   SOC:  phi = (1/2mu)(|Proj(lam - mu v)|^2 - |lam|^2);  d phi/dv = -Proj(lb),  phi_vv = mu J_Proj(lb)
+//         (with the projection-curvature term; Gauss-Newton only: mu J_Proj^2 -- same block shape)
+// The quad's 4 values are gathered with DPP, so this must run with EXEC all ones.
+template <bool HESS>
+__device__ __forceinline__ ConeEval cone_eval(double v, double lam, double mu, const ConMeta& cm, bool act,
+                                              double dual_max, bool second_order) {
+  ConeEval e;
+  const bool is_soc = cm.type == CT_SOC;
+  // a linear row may sit in a spare lane of a cone's quad: it never takes part in the cone
+  const bool row_on = act & (is_soc ? (cm.pos < cm.p) : (cm.type != CT_NONE));
+  // ---- linear rows
+  const bool a_in = (cm.type == CT_EQ) | (v >= 0.0) | (lam > 0.0);
+  const double lin_g = lam + (a_in ? mu * v : 0.0);
+  const double lin_m = a_in ? mu : 0.0;
+  const double lin_cost = lam * v + (a_in ? 0.5 * mu * v * v : 0.0);
+  const double lin_viol = (cm.type == CT_EQ) ? fabs(v) : fmax(v, 0.0);
+  const double lin_lo = (cm.type == CT_EQ) ? -dual_max : 0.0;
+  const double lin_new = fmin(fmax(lam + mu * v, lin_lo), dual_max);
+  // ---- second-order cone: gather the quad
+  const double lb = (row_on & is_soc) ? (lam - mu * v) : 0.0;
+  const double vv = (row_on & is_soc) ? v : 0.0;
+  double lq[4], vq[4];
+  lq[0] = quad_bcast<0>(lb); lq[1] = quad_bcast<1>(lb); lq[2] = quad_bcast<2>(lb); lq[3] = quad_bcast<3>(lb);
+  vq[0] = quad_bcast<0>(vv); vq[1] = quad_bcast<1>(vv); vq[2] = quad_bcast<2>(vv); vq[3] = quad_bcast<3>(vv);
+  const int pt = cm.p - 1;  // index of the t row
+  double n2 = 0.0, n2v = 0.0, t = 0.0, tv = 0.0;
+  sfor<0, 4>([&](auto q) {
+    constexpr int Q = decltype(q)::value;
+    n2 += (Q < pt) ? lq[Q] * lq[Q] : 0.0;
+    n2v += (Q < pt) ? vq[Q] * vq[Q] : 0.0;
+    t = (Q == pt) ? lq[Q] : t;
+    tv = (Q == pt) ? vq[Q] : tv;
+  });
+  const double nv = sqrt(n2), nvv = sqrt(n2v);
+  const bool inside = nv <= t, polar = (!inside) & (nv <= -t);
+  const bool bnd = !(inside | polar);
+  const double nvs = bnd ? nv : 1.0;
+  const double rn = 1.0 / nvs;
+  const double c = 0.5 * (1.0 + t * rn);
+  const bool is_t = cm.pos == pt, is_s = cm.pos < pt;
+  const double pb = is_t ? c * nv : c * lb;               // boundary projection of this row
+  const double proj = inside ? lb : (polar ? 0.0 : pb);
+  const double soc_cost = (proj * proj - lam * lam) / (2.0 * mu);
+  // violation: |Proj(v) - v| of this row
+  const bool inside_v = nvv <= tv, polar_v = (!inside_v) & (nvv <= -tv);
+  const double nvvs = (inside_v | polar_v) ? 1.0 : nvv;
+  const double cv = 0.5 * (1.0 + tv / nvvs);
+  const double pv = inside_v ? vv : (polar_v ? 0.0 : (is_t ? cv * nvv : cv * vv));
+  const double soc_viol = fabs(pv - vv);
+  e.cost = row_on ? (is_soc ? soc_cost : lin_cost) : 0.0;
+  e.viol = row_on ? (is_soc ? soc_viol : lin_viol) : 0.0;
+  e.g = row_on ? (is_soc ? -proj : lin_g) : 0.0;
+  e.lam_new = is_soc ? proj : lin_new;
+  if constexpr (HESS) {
+    // row of M: linear rows diag; SOC boundary: [[a I + b s s', s/(2nv)], [s'/(2nv), 1/2]] * mu
+    //   with curvature term (a, b) = (c, -t/(2 nv^3)); Gauss-Newton (a, b) = (c^2, (nv^2 - 2 t nv - t^2)/(4 nv^4))
+    const double rn2 = rn * rn;
+    const double a_ = second_order ? c : c * c;
+    const double b_ = second_order ? (-0.5 * t * rn * rn2) : (0.25 * (n2 - 2.0 * t * nv - t * t) * rn2 * rn2);
+    sfor<0, 4>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      const bool qs = Q < pt, qt = Q == pt;
+      const double dlt = (cm.pos == Q) ? 1.0 : 0.0;
+      double mb = 0.0;  // boundary case entry J[pos][Q] (or J^2)
+      mb = (is_s & qs) ? (a_ * dlt + b_ * lb * lq[Q]) : mb;
+      mb = (is_s & qt) ? (0.5 * lb * rn) : mb;
+      mb = (is_t & qs) ? (0.5 * lq[Q] * rn) : mb;
+      mb = (is_t & qt) ? 0.5 : mb;
+      const double ms = inside ? dlt : (polar ? 0.0 : mb);
+      const double ml = dlt * lin_m;
+      e.m[Q] = row_on ? ((is_soc ? mu * ms : ml)) : 0.0;
+    });
+  }
+  return e;
+}
+
 // Row state: everything the per-instance control flow of solve!() carries between phases.
 // One per row, in LDS (all 16 lanes of a row read the same words: LDS broadcast).
 enum { PH_STEP_BEGIN = 0, PH_OUTER_BEGIN = 1, PH_ITER = 2, PH_DONE = 3 };
@@ -202,7 +315,7 @@ struct RowState {
   int nbw, nro, nsolve, nit, nok, ntr;
 };
 
-template <int NX, int NU>
+template <int NX, int NU, bool CONES>
 struct Solver {
   static constexpr int NZ = NX + NU;
   static_assert(NZ <= LW, "packed kernel needs n + m <= 16");
@@ -240,6 +353,33 @@ struct Solver {
     }
     ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
   }
+
+  // ---- generic constraint rows (CONES): this lane owns constraint row j
+  __device__ __forceinline__ ConMeta con_meta() const {
+    ConMeta cm;
+    cm.type = P.cmeta[j * 4 + 0];
+    cm.k0 = P.cmeta[j * 4 + 1];
+    cm.k1 = P.cmeta[j * 4 + 2];
+    cm.p = P.cmeta[j * 4 + 3];
+    cm.pos = j & 3;
+    return cm;
+  }
+  // row j of Acon (coefficients of z_0..z_NZ-1) for value = Acon z + bcon
+  __device__ __forceinline__ void con_row(double (&arow)[NZ], double& brow) const {
+    sfor<0, NZ>([&](auto c) { arow[decltype(c)::value] = P.Acon[j * LW + decltype(c)::value]; });
+    brow = P.bcon[j];
+  }
+  // column j of Acon (coefficient of z_j in every constraint row)
+  __device__ __forceinline__ void con_col(double (&acol)[16]) const {
+    sfor<0, 16>([&](auto r) { acol[decltype(r)::value] = P.Acon[decltype(r)::value * LW + j]; });
+  }
+  // constraint values of this lane's row for the knot vector z (one element per lane)
+  __device__ __forceinline__ double con_value(double z, const double (&arow)[NZ], double brow) const {
+    double acc4[4] = {brow, 0.0, 0.0, 0.0};
+    Blk<NX, NU>::GZ(acc4, z, arow);
+    return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+  }
+  static __device__ __forceinline__ bool con_act(const ConMeta& cm, int k) { return (k >= cm.k0) & (k <= cm.k1); }
 
   __device__ __forceinline__ LaneConst consts() const {
     LaneConst c;
@@ -303,6 +443,7 @@ struct Solver {
   struct KnotIn {
     double z, zr, lhi, llo;
     double kcol[NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] in kcol[a]
+    double lc;        // dual of this lane's constraint row (CONES)
   };
 
   // rollout!(solver[, alpha]) fused with cost!(obj, Z̄) and max_violation.
@@ -334,6 +475,15 @@ struct Solver {
     const bool shl = OPEN && shift;           // per row
     const bool shu = shl && !is_x;            // controls are read one knot ahead
     const bool wr_l = OPEN && shift && take;  // shifted duals are written back
+    // generic constraint rows: this lane's row of Acon stays in registers for the sweep
+    ConMeta cm{};
+    double arow[NZ], brow = 0.0;
+    if constexpr (CONES) {
+      cm = con_meta();
+      con_row(arow, brow);
+    }
+    const double dmax = P.o.dual_max;
+    const bool so2 = P.o.soc_second_order != 0;
 
     // operands of stage knot k (k clamped to 0..N-2 by the callers)
     auto load = [&](int k, KnotIn& in) {
@@ -347,6 +497,8 @@ struct Solver {
       if constexpr (!OPEN) {
         sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
       }
+      in.lc = 0.0;
+      if constexpr (CONES) in.lc = ldg(P.Lc, at(shl ? imin(k + 1, cm.k1) : k));
     };
 
     auto stage = [&](int k, const KnotIn& in) {
@@ -384,6 +536,14 @@ struct Solver {
         stg(P.Z, zd + at(k), zb);
       }
       Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
+      if constexpr (CONES) {
+        const bool act = con_act(cm, k);
+        const double v = con_value(zb, arow, brow);
+        const ConeEval e = cone_eval<false>(v, act ? in.lc : 0.0, mu, cm, act, dmax, so2);
+        Jacc += e.cost;
+        viol = fmax(viol, e.viol);
+        if constexpr (OPEN) stg(P.Lc, (wr_l & act) ? at(k) : at(P.N), in.lc);
+      }
       const double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
       limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
@@ -395,8 +555,9 @@ struct Solver {
     const int kt = N - 1;
     const double t_zr = ldg(P.Zref, at(kref + kt));
     const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
-    double t_z = 0.0;
+    double t_z = 0.0, t_lc = 0.0;
     if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
+    if constexpr (CONES) t_lc = ldg(P.Lc, at(kt));
 
     // software pipeline: operands of knot k+PD are requested right after knot k is consumed.
     // The main loop body is one basic block (PD stages, PD clamped loads).
@@ -428,6 +589,13 @@ struct Solver {
       if constexpr (OPEN) stg(P.Z, take ? (zd + at(kt)) : trash_z(), zb);
       else stg(P.Z, zd + at(kt), zb);
       Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
+      if constexpr (CONES) {
+        const bool act = con_act(cm, kt);
+        const double v = con_value(zb, arow, brow);
+        const ConeEval e = cone_eval<false>(v, act ? t_lc : 0.0, mu, cm, act, dmax, so2);
+        Jacc += e.cost;
+        viol = fmax(viol, e.viol);
+      }
       limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
       if constexpr (!OPEN) changed = changed | (is_x & (zb != t_z));
     }
@@ -500,11 +668,19 @@ struct Solver {
     });
     const bool live = is_x | is_u;
     const double lm = is_x ? P.o.max_state_value : P.o.max_control_value;
+    ConMeta cm{};
+    double arow[NZ], brow = 0.0;
+    if constexpr (CONES) {
+      cm = con_meta();
+      con_row(arow, brow);
+    }
+    const double dmax = P.o.dual_max;
+    const bool so2 = P.o.soc_second_order != 0;
     constexpr int UN = ALTRO_UN;
     const int nch = (N + UN - 1) / UN;
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * UN;
-      double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN];
+      double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN], lcq[UN];
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = imin(k0 + Q, N - 1);
@@ -513,6 +689,8 @@ struct Solver {
         zr[Q] = ldg(P.Zref, at(kref + k));
         lhi[Q] = ldg(P.Lb, lb_at(k, 0));
         llo[Q] = ldg(P.Lb, lb_at(k, 1));
+        lcq[Q] = 0.0;
+        if constexpr (CONES) lcq[Q] = ldg(P.Lc, at(k));
       });
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
@@ -524,9 +702,22 @@ struct Solver {
         const double w = valid ? (term ? lc.wf : lc.wd) : 0.0;
         const bool on = (term ? is_x : live) & valid;
         const double lh = bx ? lhi[Q] : 0.0, ll = bx ? llo[Q] : 0.0;
+        // constraint values are affine in alpha as well: v(alpha) = v(Z) + alpha (v(Z1) - v(Z))
+        double cv0 = 0.0, cdv = 0.0;
+        bool cact = false;
+        if constexpr (CONES) {
+          cact = con_act(cm, k) & valid;
+          cv0 = con_value(on ? z[Q] : 0.0, arow, brow);
+          cdv = con_value(on ? zz1[Q] : 0.0, arow, brow) - cv0;
+        }
         sfor<0, NA>([&](auto t) {
           constexpr int Tt = decltype(t)::value;
           const double zb = on ? __builtin_fma(a[Tt], dz, z[Q]) : 0.0;
+          if constexpr (CONES) {
+            const ConeEval e = cone_eval<false>(__builtin_fma(a[Tt], cdv, cv0), cact ? lcq[Q] : 0.0, mu, cm, cact, dmax, so2);
+            Jacc[Tt] += e.cost;
+            viol[Tt] = fmax(viol[Tt], e.viol);
+          }
           Jacc[Tt] += lane_cost(lc, mu, zb, on ? zr[Q] : 0.0, w, lh, ll, bx & on, viol[Tt]);
           lim[Tt] = lim[Tt] | (on & !(fabs(zb) <= lm));
           chg[Tt] = chg[Tt] | (on & (zb != z[Q]));
@@ -608,7 +799,30 @@ struct Solver {
       g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
     });
     const int N = P.N;
-    // terminal expansion: S = Qf (+ box hessian), s = Qf (x - xr) (+ box gradient)
+    // generic constraint rows: row j and column j of Acon stay in registers for the pass
+    ConMeta cm{};
+    double arow[NZ], brow = 0.0, acol[16];
+    if constexpr (CONES) {
+      cm = con_meta();
+      con_row(arow, brow);
+      con_col(acol);
+    }
+    const double dmax = P.o.dual_max;
+    const bool so2 = P.o.soc_second_order != 0;
+    // conic AL expansion at one knot: gradient A'g added to qz, Hessian A' M A added to hh
+    auto cone_expand = [&](int k, double z, double lam, double& qz, double (&hh)[NZ]) {
+      const bool act = con_act(cm, k);
+      const double v = con_value(z, arow, brow);
+      const ConeEval e = cone_eval<true>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+      BlkCommon::RS16(a4, e.g, acol);
+      qz += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      double y[16];
+      sfor<0, 16>([&](auto r) { y[decltype(r)::value] = 0.0; });
+      BlkCommon::YM(y, e.m, acol);
+      Blk<NX, NU>::HC(hh, acol, y);
+    };
+    // terminal expansion: S = Qf (+ box / cone hessian), s = Qf (x - xr) (+ box / cone gradient)
     double Sx[NX + 1];
     {
       const int k = N - 1;
@@ -617,10 +831,20 @@ struct Solver {
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       double qz = lc.wf * (z - zr), hz = lc.wf;
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz);
-      sfor<0, NX>([&](auto c) {
-        constexpr int C = decltype(c)::value;
-        Sx[C] = (j == C) ? hz : 0.0;
-      });
+      if constexpr (CONES) {
+        double hT[NZ];
+        sfor<0, NZ>([&](auto c) {
+          constexpr int C = decltype(c)::value;
+          hT[C] = (j == C) ? hz : 0.0;
+        });
+        cone_expand(k, is_x ? z : 0.0, ldg(P.Lc, at(k)), qz, hT);
+        sfor<0, NX>([&](auto c) { Sx[decltype(c)::value] = hT[decltype(c)::value]; });
+      } else {
+        sfor<0, NX>([&](auto c) {
+          constexpr int C = decltype(c)::value;
+          Sx[C] = (j == C) ? hz : 0.0;
+        });
+      }
       Sx[NX] = is_x ? qz : 0.0;
     }
     dV1 = 0.0;
@@ -630,11 +854,15 @@ struct Solver {
     // operands of the knot about to be processed (loaded one knot ahead)
     double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
     double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
+    double lcc = 0.0;
+    if constexpr (CONES) lcc = ldg(P.Lc, at(N - 2));
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + at(km));
       const double zrn = ldg(P.Zref, at(kref + km));
       const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
+      double lcn = 0.0;
+      if constexpr (CONES) lcn = ldg(P.Lc, at(km));
       double qz = lc.wd * (z - zr), hz = lc.wd;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
@@ -647,6 +875,7 @@ struct Solver {
         constexpr int C = decltype(c)::value;
         h[C] = (j == C) ? hz : 0.0;
       });
+      if constexpr (CONES) cone_expand(k, (is_x | is_u) ? z : 0.0, lcc, qz, h);
       Blk<NX, NU>::GtW(h, g, w);
       const double gz = qz + w[NX];  // Qx[j] on x lanes, Qu[a] on u lanes
       // gather Quu (lower triangle) and Qu to every lane
@@ -758,6 +987,7 @@ struct Solver {
       zr = zrn;
       lhi = lhin;
       llo = llon;
+      lcc = lcn;
     }
   }
 
@@ -775,6 +1005,22 @@ struct Solver {
       const double nlo = fmin(fmax(llo + mu * (lc.zmin - z), 0.0), dmax);
       stg(P.Lb, (upd & on & lc.has_hi) ? lb_at(k, 0) : trash_l(0), nhi);
       stg(P.Lb, (upd & on & lc.has_lo) ? lb_at(k, 1) : trash_l(1), nlo);
+    }
+    if constexpr (CONES) {  // dual_update! of the generic rows: eq / ineq clamp, SOC projection
+      const ConMeta cm = con_meta();
+      double arow[NZ], brow;
+      con_row(arow, brow);
+      const bool so2 = P.o.soc_second_order != 0;
+      for (int k = 0; k < P.N; ++k) {
+        const bool live = (k < P.N - 1) ? (is_x | is_u) : is_x;
+        const double z = ldg(P.Z, zs + at(k));
+        const double lam = ldg(P.Lc, at(k));
+        const bool act = con_act(cm, k);
+        const double v = con_value(live ? z : 0.0, arow, brow);
+        const ConeEval e = cone_eval<false>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
+        const bool row_on = act & ((cm.type == CT_SOC) ? (cm.pos < cm.p) : (cm.type != CT_NONE));
+        stg(P.Lc, (upd & row_on) ? at(k) : at(P.N), e.lam_new);
+      }
     }
   }
 
@@ -808,7 +1054,7 @@ struct Solver {
     const altro_opts& o = P.o;
     const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
     const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
-    const bool has_con = P.box_k1 >= P.box_k0;
+    const bool has_con = (P.box_k1 >= P.box_k0) || (CONES && P.ncrows > 0);
     const int n_outer = has_con ? o.iterations_outer : 1;
     {  // row state init (every lane of the row writes the same words)
       RowState s;
@@ -838,6 +1084,9 @@ struct Solver {
             for (int k = P.box_k0; k <= P.box_k1; ++k) {
               stg(P.Lb, (go & bounded) ? lb_at(k, 0) : trash_l(0), 0.0);
               stg(P.Lb, (go & bounded) ? lb_at(k, 1) : trash_l(1), 0.0);
+            }
+            if constexpr (CONES) {
+              for (int k = 0; k < P.N; ++k) stg(P.Lc, go ? at(k) : at(P.N), 0.0);
             }
           }
           if (begin) {
@@ -1120,12 +1369,12 @@ struct Solver {
 // nsteps == 0: solve!(altro).  nsteps > 0: that many consecutive MPC steps of every instance,
 // each in the reference's order (random_linear_problem.jl:125-139,161): plant step + noise -> x0;
 // reference window <- step+1; shift_fill primal and dual; solve.
-template <int NX, int NU>
+template <int NX, int NU, bool CONES>
 __global__ void __launch_bounds__(64, ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
   const long long t0 = __builtin_amdgcn_s_memtime();
-  Solver<NX, NU> s(p, rows, tiles);
+  Solver<NX, NU, CONES> s(p, rows, tiles);
   s.run(p.nsteps > 0, p.first_step, p.nsteps);
   s.finish();
   const long long t1 = __builtin_amdgcn_s_memtime();

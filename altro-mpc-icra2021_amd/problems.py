@@ -78,3 +78,88 @@ def gen_random_linear_batch(batch, n=12, m=4, N=50, steps=100, dt=0.1, seed=1, f
         X[:, k + 1] = np.einsum("bij,bj->bi", A, X[:, k]) + np.einsum("bij,bj->bi", Bm, U[:, k])
     return RandomLinearBatch(n=n, m=m, N=N, dt=dt, A=A, Bm=Bm, Xtrack=X, Utrack=U, noise=noise,
                              u_bnd=u_bnd)
+
+
+# ---------------------------------------------------------------------------------------------
+# rocket landing (BASELINE config 3): reference benchmarks/rocket_landing/rocket_landing_problem.jl
+BOX, LINEAR, SOC = 0, 1, 2
+EQ, INEQ = 0, 1
+
+
+def rocket_model(mass, grav, dt):
+    """RocketModel (:17-40) with omega_planet = 0, discretised exactly (RD.Exponential):
+    x = [r; v], x+ = A x + B u + f."""
+    I3, Z3 = np.eye(3), np.zeros((3, 3))
+    A = np.block([[I3, dt * I3], [Z3, I3]])
+    Bm = np.vstack([0.5 * dt * dt / mass * I3, dt / mass * I3])
+    g = np.asarray(grav, dtype=float)
+    f = np.concatenate([0.5 * dt * dt * g, dt * g])
+    return A, Bm, f
+
+
+@dataclass
+class ConstraintSpec:
+    """One add_constraint! call as data: value = A z + b on knots k_first..k_last (0-based,
+    inclusive); kind BOX / LINEAR / SOC, sense EQ / INEQ for LINEAR."""
+    kind: int
+    sense: int
+    k_first: int
+    k_last: int
+    A: np.ndarray = None
+    b: np.ndarray = None
+    zmin: np.ndarray = None
+    zmax: np.ndarray = None
+
+
+@dataclass
+class RocketProblemData:
+    n: int
+    m: int
+    N: int
+    dt: float
+    A: np.ndarray
+    Bm: np.ndarray
+    f: np.ndarray
+    Q: np.ndarray
+    R: np.ndarray
+    Qf: np.ndarray
+    xf: np.ndarray
+    x0: np.ndarray
+    U0: np.ndarray
+    constraints: list
+
+
+def gen_rocket_problem(N=101, tf=10.0, x0=(4.0, 2.0, 20.0, -3.0, 2.0, -5.0), Qk=1e-2, Qfk=100.0, Rk=1e-1,
+                       gravity=(0.0, 0.0, -9.81), mass=10.0, perWeightMax=2.0, theta_thrust_max=7.0,
+                       theta_glideslope=60.0, glide_recover_k=8, include_goal=True, include_thrust_angle=True,
+                       include_glideslope=True):
+    """RocketProblem (:44-186).  NormConstraint2's value [A y; c'y] carries zero rows for the
+    components A does not select (:136-141, :155-164); they are dropped here (same cone)."""
+    n, m = 6, 3
+    dt = tf / (N - 1)
+    A, Bm, f = rocket_model(mass, gravity, dt)
+    cons = []
+    nz = n + m
+    if include_goal:  # GoalConstraint(xf) at N (:96)
+        Ag = np.hstack([np.eye(n), np.zeros((n, m))])
+        cons.append(ConstraintSpec(LINEAR, EQ, N - 1, N - 1, A=Ag, b=np.zeros(n)))
+    u_bnd = mass * abs(gravity[2]) * perWeightMax  # :121
+    At = np.zeros((4, nz))
+    At[0, n + 0] = At[1, n + 1] = At[2, n + 2] = 1.0
+    cons.append(ConstraintSpec(SOC, 0, 0, N - 2, A=At, b=np.array([0.0, 0.0, 0.0, u_bnd])))  # :123-124
+    if include_thrust_angle:  # || (ux, uy) || <= tan(theta) uz   (:134-144)
+        a = np.tan(np.deg2rad(theta_thrust_max))
+        Aa = np.zeros((3, nz))
+        Aa[0, n + 0] = Aa[1, n + 1] = 1.0
+        Aa[2, n + 2] = a
+        cons.append(ConstraintSpec(SOC, 0, 0, N - 2, A=Aa, b=np.zeros(3)))
+    if include_glideslope:  # || (x, y) || <= tan(theta) z on knots glide_recover_k..N-1 (1-based) (:153-167)
+        a = np.tan(np.deg2rad(theta_glideslope))
+        Agl = np.zeros((3, nz))
+        Agl[0, 0] = Agl[1, 1] = 1.0
+        Agl[2, 2] = a
+        cons.append(ConstraintSpec(SOC, 0, glide_recover_k - 1, N - 2, A=Agl, b=np.zeros(3)))
+    U0 = np.tile(-mass * np.asarray(gravity, dtype=float), (N - 1, 1))  # hover (:181-183)
+    return RocketProblemData(n=n, m=m, N=N, dt=dt, A=A, Bm=Bm, f=f, Q=np.full(n, Qk), R=np.full(m, Rk),
+                             Qf=np.full(n, Qfk), xf=np.zeros(n), x0=np.asarray(x0, dtype=float), U0=U0,
+                             constraints=cons)

@@ -132,8 +132,11 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qdiag, cons
  *   BOX:    zmin, zmax of length n+m (+-inf = absent)
  *   LINEAR: A [p][n+m] ROW-major, b [p]; value A z + b {= 0 | <= 0}
  *   SOC:    A, b as above; value v = A z + b with ||v[0..p-2]|| <= v[p-1]
- *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67)
- * Constraint data is shared by all instances of the batch. */
+ *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67) -- not
+ *                  built yet in the HIP library (ALTRO_ERR_UNSUPPORTED)
+ * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; the
+ * LINEAR / SOC rows of a knot fit 4 quads of 4 rows (an SOC of dimension 2..4 takes one quad,
+ * p linear rows take ceil(p/4)). */
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first,
                                    int32_t k_last, int32_t p, const double* A, const double* b,
                                    const double* zmin, const double* zmax, int32_t per_knot,
@@ -164,8 +167,8 @@ int32_t altro_batch_synchronize(altro_handle* h);
 /* states(solver), controls(solver), Altro.get_duals: random_linear_problem.jl:177-181 */
 int32_t altro_batch_get_states(altro_handle* h, double* X);
 int32_t altro_batch_get_controls(altro_handle* h, double* U);
-/* duals of one constraint: BOX -> [batch][nk][2][n+m] (upper rows, then lower rows),
- * LINEAR/SOC -> [batch][nk][p] */
+/* duals of one constraint: BOX -> [batch][nk][2][n+m] (upper rows, then lower rows; zero for
+ * unbounded elements), LINEAR/SOC -> [batch][nk][p] */
 int32_t altro_batch_get_duals(altro_handle* h, int32_t con_id, double* lambda);
 int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lambda);
 

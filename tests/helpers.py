@@ -60,3 +60,87 @@ def condensed_qp(A, Bm, x0, Xref, Uref, Qd, Rd, Qfd, dt, u_bnd):
     U = res.x.reshape(N - 1, m)
     X = (Phi @ x0 + Gam @ res.x).reshape(N, n)
     return X, U, res
+
+
+# ---------------------------------------------------------------------------------------------
+# rocket landing (second-order cones + goal): oracle / GPU set-up shared by the tests
+ROCKET_COLD_OPTS = dict(cost_tolerance_intermediate=1e-4, penalty_scaling=500.0, penalty_initial=1e-2,
+                        constraint_tolerance=1e-5, iterations=5000, iterations_inner=100,
+                        iterations_linesearch=100, iterations_outer=60)
+"""run_simple_rocket.jl:39-50 (iterations_outer 500 there; 60 is never reached)"""
+ROCKET_MPC_OPTS = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-4,
+                       reset_duals=0, penalty_initial=1000.0, penalty_scaling=10.0)
+"""run_simple_rocket.jl:121-129"""
+
+
+def rocket_oracle(O, rp, x0, opts, Xref=None, Uref=None, U0=None, constraints=None):
+    s = O.OracleSolver(rp.n, rp.m, rp.N, rp.dt)
+    s.set_dynamics(rp.A, rp.Bm, rp.f)
+    s.set_cost(rp.Q, rp.R, rp.Qf)
+    s.set_reference(np.tile(rp.xf, (rp.N, 1)) if Xref is None else Xref,
+                    np.zeros((rp.N - 1, rp.m)) if Uref is None else Uref)
+    s.set_initial_state(x0)
+    s.set_controls(rp.U0 if U0 is None else U0)
+    s.con_ids = []
+    for c in (rp.constraints if constraints is None else constraints):
+        s.con_ids.append(s.add_affine(c.kind, c.sense, c.A, c.b, c.k_first, c.k_last))
+    s.set_opts(O.default_opts(**opts))
+    return s
+
+
+def rocket_gpu_problem(altro, rp, x0, Xref=None, Uref=None, U0=None, constraints=None):
+    from altro_mpc_icra2021_amd import problems as P
+    B = x0.shape[0]
+    model = altro.LinearModel(rp.A, rp.Bm, rp.f, dt=rp.dt)
+    Xr = np.tile(rp.xf, (B, rp.N, 1)) if Xref is None else Xref
+    Ur = np.zeros((B, rp.N - 1, rp.m)) if Uref is None else Uref
+    obj = altro.TrackingObjective(rp.Q, rp.R, rp.Qf, Xr, Ur)
+    cons = altro.ConstraintList(rp.n, rp.m, rp.N)
+    for c in (rp.constraints if constraints is None else constraints):
+        con = altro.NormConstraint(c.A, c.b) if c.kind == P.SOC else altro.LinearConstraint(c.A, c.b, equality=(c.sense == P.EQ))
+        cons.add_constraint(con, (c.k_first + 1, c.k_last + 1))
+    return altro.Problem(model, obj, cons, x0=x0, N=rp.N, U0=np.tile(rp.U0, (B, 1, 1)) if U0 is None else U0)
+
+
+def soc_project(v):
+    """Euclidean projection onto {(s, t): ||s|| <= t}."""
+    s, t = v[:-1], v[-1]
+    ns = np.linalg.norm(s)
+    if ns <= t:
+        return v.copy()
+    if ns <= -t:
+        return np.zeros_like(v)
+    c = 0.5 * (1 + t / ns)
+    return np.r_[c * s, c * ns]
+
+
+def admm_conic_qp(Pm, q, G, h, cones, rho=1.0, sigma=1e-6, iters=20000, tol=1e-9):
+    """min 1/2 x'Px + q'x  s.t.  G x + h in K,  K = product of cones [("zero"|"soc", dim), ...].
+    Operator-splitting (OSQP / COSMO form): an algorithm independent of AL-iLQR, used only to pin
+    the oracle's converged conic solutions, as the reference pins ALTRO against COSMO / ECOS
+    (simple_rocket.jl:183-203)."""
+    nvar = Pm.shape[0]
+    K = np.linalg.inv(Pm + sigma * np.eye(nvar) + rho * G.T @ G)
+    x = np.zeros(nvar)
+    z = np.zeros(G.shape[0])
+    y = np.zeros(G.shape[0])
+
+    def proj(w):   # projection onto C = K - h
+        out = np.empty_like(w)
+        i = 0
+        for kind, d in cones:
+            seg = w[i:i + d] + h[i:i + d]
+            out[i:i + d] = (0.0 if kind == "zero" else soc_project(seg)) - h[i:i + d]
+            i += d
+        return out
+
+    for it in range(iters):
+        x = K @ (sigma * x - q + G.T @ (rho * z - y))
+        zt = G @ x
+        zn = proj(zt + y / rho)
+        y = y + rho * (zt - zn)
+        rp_, rd_ = np.abs(zt - zn).max(), rho * np.abs(G.T @ (zn - z)).max()
+        z = zn
+        if it > 10 and rp_ < tol and rd_ < tol:
+            break
+    return x, it
