@@ -163,3 +163,85 @@ def gen_rocket_problem(N=101, tf=10.0, x0=(4.0, 2.0, 20.0, -3.0, 2.0, -5.0), Qk=
     return RocketProblemData(n=n, m=m, N=N, dt=dt, A=A, Bm=Bm, f=f, Q=np.full(n, Qk), R=np.full(m, Rk),
                              Qf=np.full(n, Qfk), xf=np.zeros(n), x0=np.asarray(x0, dtype=float), U0=U0,
                              constraints=cons)
+
+
+# ---------------------------------------------------------------------------------------------
+# grasp optimisation: reference benchmarks/grasp_optimization/src/{grasp_model,grasp_problem,utils}.jl
+def _rot3(th):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]])
+
+
+def _skew(a):
+    return np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+
+
+@dataclass
+class GraspProblemData:
+    n: int
+    m: int
+    N: int
+    dt: float
+    A: np.ndarray
+    Bm: np.ndarray
+    f: np.ndarray
+    Q: np.ndarray
+    R: np.ndarray
+    Qf: np.ndarray
+    xf: np.ndarray
+    x0: np.ndarray
+    U0: np.ndarray
+    constraints: list   # ConstraintSpec with per-knot A (nk, p, nz) and b (nk, p)
+    theta: np.ndarray
+    p: list             # contact points p[i][k]
+    v: list             # inward normals v[i][k]
+
+
+def gen_grasp_problem(N=61, tf=6.0, x0=(0.0, 3.0, 3.0, 0.0, 0.0, 0.0), mu=0.5, mass=0.2, f_max=3.0,
+                      theta0=0.0, thetaf=np.pi / 4, thetad0=0.0, thetadf=0.15):
+    """GraspProblem (grasp_problem.jl:1-107) for the SquareObject of grasp_model.jl:4-92.
+    Two fingers hold a rotating block: per-knot torque balance (equality), max normal force
+    (inequality) and two friction cones ||(I - v v')F_i|| <= mu v'F_i (second-order cones)."""
+    n = m = 6
+    dt = tf / (N - 1)
+    g = np.array([0.0, 0.0, -9.81])
+    I3, Z3 = np.eye(3), np.zeros((3, 3))
+    A = np.block([[I3, dt * I3], [Z3, I3]])                                   # grasp_model.jl:74-92
+    Bm = np.vstack([0.5 * dt * dt / mass * np.hstack([I3, I3]), dt / mass * np.hstack([I3, I3])])
+    f = np.concatenate([0.5 * dt * dt * g, dt * g])
+    # cubic orientation trajectory (utils.jl:23-31, grasp_model.jl:33-41)
+    t0 = 0.0
+    M = np.array([[t0**3, t0**2, t0, 1], [tf**3, tf**2, tf, 1], [3 * t0**2, 2 * t0, 1, 0], [3 * tf**2, 2 * tf, 1, 0]])
+    c = np.linalg.solve(M, np.array([theta0, thetaf, thetad0, thetadf]))
+    ts = np.arange(N) * dt
+    theta = c[0] * ts**3 + c[1] * ts**2 + c[2] * ts + c[3]
+    thetadd = 6 * c[0] * ts + 2 * c[1]
+    p10, v10 = np.array([0.0, -1.0, 0.0]), np.array([0.0, 1.0, 0.0])        # grasp_model.jl:44-49 (last assignments)
+    p20, v20 = np.array([0.0, 1.0, 0.0]), np.array([0.0, -1.0, 0.0])
+    p = [[_rot3(th) @ p10 for th in theta], [_rot3(th) @ p20 for th in theta]]
+    v = [[_rot3(th) @ v10 for th in theta], [_rot3(th) @ v20 for th in theta]]
+    nz = n + m
+    nk = N - 1
+    At = np.zeros((nk, 3, nz)); bt = np.zeros((nk, 3))
+    Ag = np.zeros((nk, 2, nz)); bg = np.full((nk, 2), -f_max)
+    Af = [np.zeros((nk, 4, nz)), np.zeros((nk, 4, nz))]
+    for k in range(nk):
+        At[k, :, n:n + 3] = _skew(p[0][k]); At[k, :, n + 3:] = _skew(p[1][k])   # torque balance (:35-38)
+        bt[k] = -np.array([thetadd[k], 0.0, 0.0])
+        Ag[k, 0, n:n + 3] = v[0][k]; Ag[k, 1, n + 3:] = v[1][k]                 # max normal force (:41-49)
+        for i in range(2):                                                       # friction cones (:52-67)
+            vv = v[i][k]
+            Af[i][k, :3, n + 3 * i:n + 3 * i + 3] = np.eye(3) - np.outer(vv, vv)
+            Af[i][k, 3, n + 3 * i:n + 3 * i + 3] = mu * vv
+    xf = np.zeros(n)
+    cons = [
+        ConstraintSpec(LINEAR, EQ, N - 1, N - 1, A=np.hstack([np.eye(n), np.zeros((n, m))]), b=-xf),   # goal (:29-30)
+        ConstraintSpec(LINEAR, EQ, 0, N - 2, A=At, b=bt),
+        ConstraintSpec(LINEAR, INEQ, 0, N - 2, A=Ag, b=bg),
+        ConstraintSpec(SOC, 0, 0, N - 2, A=Af[0], b=np.zeros((nk, 4))),
+        ConstraintSpec(SOC, 0, 0, N - 2, A=Af[1], b=np.zeros((nk, 4))),
+    ]
+    u0 = np.array([0.0, -1.5, mass * 9.81 / 2, 0.0, 1.5, mass * 9.81 / 2])      # :101-104
+    return GraspProblemData(n=n, m=m, N=N, dt=dt, A=A, Bm=Bm, f=f, Q=np.full(n, 1e-3), R=np.full(m, 1.0),
+                            Qf=np.full(n, 10.0), xf=xf, x0=np.asarray(x0, dtype=float),
+                            U0=np.tile(u0, (N - 1, 1)), constraints=cons, theta=theta, p=p, v=v)
