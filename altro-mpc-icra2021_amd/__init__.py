@@ -11,5 +11,5 @@ from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, Goal
                   LinearModel, NormConstraint, Problem,  # noqa: F401
                   SolverOptions, TrackingObjective, controls, cost, get_duals, initial_controls,
                   iterations, max_violation, set_duals, set_initial_state, set_options, shift_fill,
-                  solve, solve_counters, states, stats, status, timing_get, timing_reset, update_trajectory,
+                  solve, solve_counters, states, stats, status, timing_get, timing_reset, update_constraint_data, update_trajectory,
                   wave_cycles, work_counters)

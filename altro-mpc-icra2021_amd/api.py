@@ -186,13 +186,15 @@ class ALTROSolver:
                 self.con_ids.append(cid.value)
             elif isinstance(con, (LinearConstraint, NormConstraint)):
                 A, b = _c(con.A), _c(con.b)
-                assert A.shape == (b.shape[0], n + m)
+                per_knot = A.ndim == 3            # (nk, p, n+m): LinearConstraintTraj / AffineSOCTraj
+                assert A.shape[-1] == n + m and A.shape[:-1] == b.shape
+                assert not per_knot or A.shape[0] == last - first + 1
                 soc = isinstance(con, NormConstraint)
                 kind = _lib.CON_SOC if soc else _lib.CON_LINEAR
                 sense = _lib.SENSE_EQ if (not soc and con.equality) else _lib.SENSE_INEQ
                 cid = C.c_int32(-1)
-                self._chk(L.altro_batch_add_constraint(h, kind, sense, first - 1, last - 1, A.shape[0],
-                                                       _p(A), _p(b), None, None, 0, C.byref(cid)))
+                self._chk(L.altro_batch_add_constraint(h, kind, sense, first - 1, last - 1, A.shape[-2],
+                                                       _p(A), _p(b), None, None, int(per_knot), C.byref(cid)))
                 self.con_ids.append(cid.value)
             else:
                 raise AltroError(_lib.ERR_UNSUPPORTED, f"constraint type {type(con).__name__} is not built yet")
@@ -268,7 +270,7 @@ def get_duals(solver, con=0):
     if isinstance(c, BoundConstraint):
         lam = np.empty((solver.B, nk, 2, solver.n + solver.m))
     else:
-        lam = np.empty((solver.B, nk, np.asarray(c.b).shape[0]))
+        lam = np.empty((solver.B, nk, np.asarray(c.b).shape[-1]))
     solver._chk(solver._L.altro_batch_get_duals(solver.h, solver.con_ids[con], _p(lam)))
     return lam
 
@@ -363,3 +365,9 @@ def solve_counters(solver):
     a = [np.zeros(solver.B, dtype=np.int64) for _ in range(3)]
     solver._chk(solver._L.altro_batch_get_solve_counters(solver.h, *[x.ctypes.data_as(i64) for x in a]))
     return tuple(a)
+
+
+def update_constraint_data(solver, con, A=None, b=None):
+    """In-place mutation of a constraint's (per-knot) data: grasp_mpc_helpers.jl:46-55."""
+    solver._chk(solver._L.altro_batch_update_constraint_data(
+        solver.h, solver.con_ids[con], _p(_c(A)) if A is not None else None, _p(_c(b)) if b is not None else None))

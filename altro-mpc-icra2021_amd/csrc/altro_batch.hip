@@ -51,14 +51,14 @@ struct altro_handle {
   // generic affine constraints packed into 4 quads of 4 constraint rows (see solve_dpp16.h)
   double *Acon = nullptr, *bcon = nullptr, *Lc = nullptr;
   int* cmeta = nullptr;
-  double Acon_h[LW * LW];
-  double bcon_h[LW];
-  int cmeta_h[LW * 4];
+  std::vector<double> Acon_h, bcon_h;  // per-knot tables [N][16][16], [N][16]
+  std::vector<int> cmeta_h;            // [N][16][4]
   int ncrows = 0;       // 16 once any generic constraint exists (kernel flag)
   bool con_dirty = false, con_locked = false;  // packing is redone until the first solve
   struct ConBlock {
     int id, kind, sense, k0, k1, p;
-    std::vector<double> A, b;  // A row-major p x nz
+    int per_knot;
+    std::vector<double> A, b;  // A row-major p x nz, one block per knot of the range if per_knot
     int lanes[LW];
   };
   std::vector<ConBlock> cons;
@@ -246,9 +246,11 @@ __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, si
       for (int k = k0; k < k1; ++k) l[(size_t)k * ls] = l[(size_t)(k + 1) * ls];
     }
   }
-  if (dual && j < ncrows) {  // generic constraint row j: its own knot range
-    const int c0 = cmeta[4 * j + 1], c1 = cmeta[4 * j + 2];
-    for (int k = c0; k < c1; ++k) Lc[(size_t)k * ks + off] = Lc[(size_t)(k + 1) * ks + off];
+  if (dual && j < ncrows) {  // generic constraint rows on lane j: each constraint shifts inside its own range
+    for (int k = 0; k < N - 1; ++k) {
+      const int* cm = cmeta + ((size_t)k * LW + j) * 4;
+      if (cm[0] != 0 && k < cm[2]) Lc[(size_t)k * ks + off] = Lc[(size_t)(k + 1) * ks + off];
+    }
   }
 }
 
@@ -417,17 +419,18 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   h->nbp = 1;
   CCHK(hipMalloc(&h->Lb, (N + 1) * Bp * 2 * h->nbp * sizeof(double)));
   CCHK(hipMalloc(&h->bslot, LW * sizeof(int)));
-  CCHK(hipMalloc(&h->Acon, LW * LW * sizeof(double)));
-  CCHK(hipMalloc(&h->bcon, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->cmeta, LW * 4 * sizeof(int)));
+  CCHK(hipMalloc(&h->Acon, N * LW * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->bcon, N * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->cmeta, N * LW * 4 * sizeof(int)));
   CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
   CCHK(hipMalloc(&h->Lc, (N + 1) * row * sizeof(double)));
-  std::memset(h->Acon_h, 0, sizeof(h->Acon_h));
-  std::memset(h->bcon_h, 0, sizeof(h->bcon_h));
-  for (int r = 0; r < LW; ++r) { h->cmeta_h[4 * r] = 0; h->cmeta_h[4 * r + 1] = 0; h->cmeta_h[4 * r + 2] = -1; h->cmeta_h[4 * r + 3] = 0; }
-  CCHK(hipMemcpyAsync(h->Acon, h->Acon_h, sizeof(h->Acon_h), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMemcpyAsync(h->bcon, h->bcon_h, sizeof(h->bcon_h), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMemcpyAsync(h->cmeta, h->cmeta_h, sizeof(h->cmeta_h), hipMemcpyHostToDevice, h->stream));
+  h->Acon_h.assign(N * LW * LW, 0.0);
+  h->bcon_h.assign(N * LW, 0.0);
+  h->cmeta_h.assign(N * LW * 4, 0);
+  for (size_t e = 0; e < N * LW; ++e) h->cmeta_h[4 * e + 2] = -1;
+  CCHK(hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CCHK(hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CCHK(hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CCHK(hipMemsetAsync(h->Lc, 0, (N + 1) * row * sizeof(double), h->stream));
   CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
@@ -536,55 +539,76 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const d
   return ALTRO_OK;
 }
 
-// Pack the recorded LINEAR / SOC constraints onto the 16 constraint-row lanes: every cone takes
-// the first p lanes of an aligned quad, linear rows fill whatever lanes remain (also the spare
-// lanes of a cone's quad).  Redone whenever a constraint is added before the first solve.
+// Pack the recorded LINEAR / SOC constraints onto the 16 constraint-row lanes and fill the per-knot
+// tables.  A constraint keeps the same lanes over its whole knot range (shift_fill moves duals
+// along the knot axis); two constraints may share lanes when their ranges do not overlap (e.g. the
+// goal at knot N-1 and the stage constraints on 0..N-2).  Every cone takes the first p lanes of an
+// aligned quad, linear rows fill whatever lanes remain (also the spare lanes of a cone's quad).
+// Redone whenever a constraint is added before the first solve.
 static int pack_constraints(altro_handle* h) {
   if (!h->con_dirty) return ALTRO_OK;
-  const int nz = h->d.n + h->d.m;
-  std::memset(h->Acon_h, 0, sizeof(h->Acon_h));
-  std::memset(h->bcon_h, 0, sizeof(h->bcon_h));
-  bool used[LW] = {false};
-  bool quad_soc[4] = {false, false, false, false};
-  for (int r = 0; r < LW; ++r) { h->cmeta_h[4 * r] = 0; h->cmeta_h[4 * r + 1] = 0; h->cmeta_h[4 * r + 2] = -1; h->cmeta_h[4 * r + 3] = 0; }
+  const int nz = h->d.n + h->d.m, N = h->d.N;
+  std::fill(h->Acon_h.begin(), h->Acon_h.end(), 0.0);
+  std::fill(h->bcon_h.begin(), h->bcon_h.end(), 0.0);
+  std::fill(h->cmeta_h.begin(), h->cmeta_h.end(), 0);
+  for (size_t e = 0; e < (size_t)N * LW; ++e) h->cmeta_h[4 * e + 2] = -1;
+  std::vector<char> used((size_t)N * LW, 0);      // lane taken at knot k
+  std::vector<char> quad_soc((size_t)N * 4, 0);   // quad holds a cone at knot k
+  auto lane_free = [&](int lane, int k0, int k1) {
+    for (int k = k0; k <= k1; ++k) if (used[(size_t)k * LW + lane]) return false;
+    return true;
+  };
   auto place = [&](altro_handle::ConBlock& cb, int r, int lane, int type, int pdim) {
     cb.lanes[r] = lane;
-    used[lane] = true;
-    for (int jj = 0; jj < nz; ++jj) h->Acon_h[lane * LW + jj] = cb.A[(size_t)r * nz + jj];
-    h->bcon_h[lane] = cb.b[r];
-    h->cmeta_h[4 * lane + 0] = type;
-    h->cmeta_h[4 * lane + 1] = cb.k0;
-    h->cmeta_h[4 * lane + 2] = cb.k1;
-    h->cmeta_h[4 * lane + 3] = pdim;
+    for (int k = cb.k0; k <= cb.k1; ++k) {
+      const size_t blk = cb.per_knot ? (size_t)(k - cb.k0) : 0;
+      const size_t e = (size_t)k * LW + lane;
+      used[e] = 1;
+      for (int jj = 0; jj < nz; ++jj) h->Acon_h[e * LW + jj] = cb.A[(blk * cb.p + r) * nz + jj];
+      h->bcon_h[e] = cb.b[blk * cb.p + r];
+      h->cmeta_h[4 * e + 0] = type;
+      h->cmeta_h[4 * e + 1] = cb.k0;
+      h->cmeta_h[4 * e + 2] = cb.k1;
+      h->cmeta_h[4 * e + 3] = pdim;
+    }
   };
   for (auto& cb : h->cons) {
     if (cb.kind != ALTRO_CON_SOC) continue;
-    int q = 0;
-    while (q < 4 && quad_soc[q]) ++q;
-    if (q == 4) FAIL(h, ALTRO_ERR_UNSUPPORTED, "more than 4 second-order cones per problem");
-    quad_soc[q] = true;
+    int q = -1;
+    for (int c = 0; c < 4 && q < 0; ++c) {
+      bool ok = true;
+      for (int k = cb.k0; k <= cb.k1 && ok; ++k) ok = !quad_soc[(size_t)k * 4 + c];
+      for (int r = 0; r < cb.p && ok; ++r) ok = lane_free(4 * c + r, cb.k0, cb.k1);
+      if (ok) q = c;
+    }
+    if (q < 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "no free quad of constraint-row lanes for a second-order cone (4 cones per knot)");
+    for (int k = cb.k0; k <= cb.k1; ++k) quad_soc[(size_t)k * 4 + q] = 1;
     for (int r = 0; r < cb.p; ++r) place(cb, r, 4 * q + r, 3, cb.p);
   }
   for (auto& cb : h->cons) {
     if (cb.kind != ALTRO_CON_LINEAR) continue;
     int lane = 0;
     for (int r = 0; r < cb.p; ++r) {
-      while (lane < LW && used[lane]) ++lane;
-      if (lane == LW) FAIL(h, ALTRO_ERR_UNSUPPORTED, "more than 16 constraint rows per knot");
+      while (lane < LW && !lane_free(lane, cb.k0, cb.k1)) ++lane;
+      if (lane == LW) FAIL(h, ALTRO_ERR_UNSUPPORTED, "more than 16 constraint rows at one knot");
       place(cb, r, lane, cb.sense == ALTRO_SENSE_EQ ? 1 : 2, 0);
     }
   }
-  // a linear row inside a cone's quad must see that cone's dimension (it is excluded by pos >= p)
-  for (int q = 0; q < 4; ++q) {
-    int pdim = 0;
-    for (int i = 0; i < 4; ++i)
-      if (h->cmeta_h[4 * (4 * q + i)] == 3) pdim = h->cmeta_h[4 * (4 * q + i) + 3];
-    for (int i = 0; i < 4; ++i) h->cmeta_h[4 * (4 * q + i) + 3] = pdim;
-  }
+  // every lane of a quad carries the dimension of the cone the quad holds at that knot (a linear
+  // row in a spare lane is excluded from the cone by pos >= p)
+  for (int k = 0; k < N; ++k)
+    for (int q = 0; q < 4; ++q) {
+      int pdim = 0;
+      for (int i = 0; i < 4; ++i) {
+        const size_t e = (size_t)k * LW + 4 * q + i;
+        if (h->cmeta_h[4 * e] == 3) pdim = h->cmeta_h[4 * e + 3];
+      }
+      for (int i = 0; i < 4; ++i) h->cmeta_h[4 * ((size_t)k * LW + 4 * q + i) + 3] = pdim;
+    }
   h->ncrows = h->cons.empty() ? 0 : LW;
-  HIPCHK(h, hipMemcpyAsync(h->Acon, h->Acon_h, sizeof(h->Acon_h), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->bcon, h->bcon_h, sizeof(h->bcon_h), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->cmeta, h->cmeta_h, sizeof(h->cmeta_h), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->con_dirty = false;
   return ALTRO_OK;
@@ -599,14 +623,15 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
   const int nz = h->d.n + h->d.m;
   if (kind == ALTRO_CON_LINEAR || kind == ALTRO_CON_SOC) {
     if (!A || !b || p < 1) return ALTRO_ERR_INVALID_ARG;
-    if (per_knot) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data is not built yet");
     if (kind == ALTRO_CON_SOC && (p < 2 || p > 4)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "second-order cones of dimension 2..4 are built");
     if (kind == ALTRO_CON_LINEAR && sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
     if (h->con_locked) FAIL(h, ALTRO_ERR_STATE, "constraints must be added before the first solve");
     altro_handle::ConBlock cb;
     cb.id = h->ncon; cb.kind = kind; cb.sense = sense; cb.k0 = k_first; cb.k1 = k_last; cb.p = p;
-    cb.A.assign(A, A + (size_t)p * nz);
-    cb.b.assign(b, b + p);
+    cb.per_knot = per_knot ? 1 : 0;
+    const size_t nblk = per_knot ? (size_t)(k_last - k_first + 1) : 1;
+    cb.A.assign(A, A + nblk * p * nz);
+    cb.b.assign(b, b + nblk * p);
     for (int r = 0; r < LW; ++r) cb.lanes[r] = -1;
     h->cons.push_back(cb);
     h->con_dirty = true;
@@ -645,9 +670,21 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
 }
 
 int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A, const double* b) {
-  (void)con_id; (void)A; (void)b;
   if (!h) return ALTRO_ERR_INVALID_ARG;
-  FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot constraint data is not built yet (constraint data is time-invariant)");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nz = h->d.n + h->d.m;
+  for (auto& cb : h->cons) {
+    if (cb.id != con_id) continue;
+    const size_t nblk = cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1;
+    if (A) cb.A.assign(A, A + nblk * cb.p * nz);
+    if (b) cb.b.assign(b, b + nblk * cb.p);
+    // same lanes, new coefficients: refresh the tables (the solver sees it at the next solve, as
+    // the reference's in-place mutation does: grasp_mpc_helpers.jl:46-55)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->con_dirty = true;
+    return pack_constraints(h);
+  }
+  FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown or non-affine constraint id");
 }
 
 int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {

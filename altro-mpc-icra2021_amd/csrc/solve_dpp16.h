@@ -94,10 +94,13 @@ struct SolveParams {
   // generic affine constraints (LINEAR eq/ineq, SOC): up to 16 constraint rows per knot, row r
   // on lane r, organised in 4 quads of 4 lanes; a quad is one cone (SOC of dimension <= 4, or
   // up to 4 independent equality / inequality rows).  Data is shared by all instances.
-  const double* Acon;    // [16][16] row-major: value_r = sum_j Acon[r][j] z_j + bcon[r]
-  const double* bcon;    // [16]
-  const int* cmeta;      // [16][4] per lane: type (0 none, 1 EQ, 2 INEQ, 3 SOC), k0, k1, p (dimension of the
-                         // cone this lane's quad holds; linear rows may use the quad's spare lanes)
+  // All tables are PER KNOT (time-varying data: grasp_problem.jl:35-67; lanes can be reused by
+  // constraints whose knot ranges do not overlap):
+  const double* Acon;    // [N][16][16] row-major: value_r = sum_j Acon[k][r][j] z_j + bcon[k][r]
+  const double* bcon;    // [N][16]
+  const int* cmeta;      // [N][16][4] per lane: type (0 none, 1 EQ, 2 INEQ, 3 SOC), k0, k1 of the row's
+                         // constraint, p (dimension of the cone this lane's quad holds at this knot;
+                         // linear rows may use the quad's spare lanes)
   double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
   int ncrows;            // 0: no generic constraints
   double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
@@ -354,24 +357,33 @@ struct Solver {
     ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
   }
 
-  // ---- generic constraint rows (CONES): this lane owns constraint row j
-  __device__ __forceinline__ ConMeta con_meta() const {
+  // ---- generic constraint rows (CONES): this lane owns constraint row j of every knot
+  struct ConK {  // this lane's row of the knot's constraint table
     ConMeta cm;
-    cm.type = P.cmeta[j * 4 + 0];
-    cm.k0 = P.cmeta[j * 4 + 1];
-    cm.k1 = P.cmeta[j * 4 + 2];
-    cm.p = P.cmeta[j * 4 + 3];
+    double arow[NZ];
+    double brow;
+  };
+  __device__ __forceinline__ ConMeta con_meta(int k) const {
+    ConMeta cm;
+    const unsigned b = ((unsigned)k * LW + j) * 4;
+    cm.type = P.cmeta[b + 0];
+    cm.k0 = P.cmeta[b + 1];
+    cm.k1 = P.cmeta[b + 2];
+    cm.p = P.cmeta[b + 3];
     cm.pos = j & 3;
     return cm;
   }
-  // row j of Acon (coefficients of z_0..z_NZ-1) for value = Acon z + bcon
-  __device__ __forceinline__ void con_row(double (&arow)[NZ], double& brow) const {
-    sfor<0, NZ>([&](auto c) { arow[decltype(c)::value] = P.Acon[j * LW + decltype(c)::value]; });
-    brow = P.bcon[j];
+  // row j of the knot's A (coefficients of z_0..z_NZ-1) for value = A z + b
+  __device__ __forceinline__ void con_load(int k, ConK& c) const {
+    c.cm = con_meta(k);
+    const unsigned b = ((unsigned)k * LW + j) * LW;
+    sfor<0, NZ>([&](auto q) { c.arow[decltype(q)::value] = ldg(P.Acon, b + decltype(q)::value); });
+    c.brow = ldg(P.bcon, (unsigned)k * LW + j);
   }
-  // column j of Acon (coefficient of z_j in every constraint row)
-  __device__ __forceinline__ void con_col(double (&acol)[16]) const {
-    sfor<0, 16>([&](auto r) { acol[decltype(r)::value] = P.Acon[decltype(r)::value * LW + j]; });
+  // column j of the knot's A (coefficient of z_j in every constraint row)
+  __device__ __forceinline__ void con_col(int k, double (&acol)[16]) const {
+    const unsigned b = (unsigned)k * LW * LW + j;
+    sfor<0, 16>([&](auto r) { acol[decltype(r)::value] = ldg(P.Acon, b + decltype(r)::value * LW); });
   }
   // constraint values of this lane's row for the knot vector z (one element per lane)
   __device__ __forceinline__ double con_value(double z, const double (&arow)[NZ], double brow) const {
@@ -379,7 +391,9 @@ struct Solver {
     Blk<NX, NU>::GZ(acc4, z, arow);
     return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   }
-  static __device__ __forceinline__ bool con_act(const ConMeta& cm, int k) { return (k >= cm.k0) & (k <= cm.k1); }
+  static __device__ __forceinline__ bool con_act(const ConMeta& cm, int k) {
+    return (cm.type != CT_NONE) & (k >= cm.k0) & (k <= cm.k1);
+  }
 
   __device__ __forceinline__ LaneConst consts() const {
     LaneConst c;
@@ -475,18 +489,11 @@ struct Solver {
     const bool shl = OPEN && shift;           // per row
     const bool shu = shl && !is_x;            // controls are read one knot ahead
     const bool wr_l = OPEN && shift && take;  // shifted duals are written back
-    // generic constraint rows: this lane's row of Acon stays in registers for the sweep
-    ConMeta cm{};
-    double arow[NZ], brow = 0.0;
-    if constexpr (CONES) {
-      cm = con_meta();
-      con_row(arow, brow);
-    }
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
 
     // operands of stage knot k (k clamped to 0..N-2 by the callers)
-    auto load = [&](int k, KnotIn& in) {
+    auto load = [&](int k, KnotIn& in, ConK& ck) {
       const int ku = imin(k + 1, N - 2);
       const int kl = imax(imin(k + 1, k1), 0);
       in.z = ldg(P.Z, zs + at(shu ? ku : k));
@@ -498,10 +505,13 @@ struct Solver {
         sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
       }
       in.lc = 0.0;
-      if constexpr (CONES) in.lc = ldg(P.Lc, at(shl ? imin(k + 1, cm.k1) : k));
+      if constexpr (CONES) {
+        con_load(k, ck);
+        in.lc = ldg(P.Lc, at(shl ? imin(k + 1, ck.cm.k1) : k));
+      }
     };
 
-    auto stage = [&](int k, const KnotIn& in) {
+    auto stage = [&](int k, const KnotIn& in, const ConK& ck) {
       const bool bx = box_at(k);
       const double lhi = bx ? in.lhi : 0.0, llo = bx ? in.llo : 0.0;
       double zb;
@@ -537,9 +547,9 @@ struct Solver {
       }
       Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
       if constexpr (CONES) {
-        const bool act = con_act(cm, k);
-        const double v = con_value(zb, arow, brow);
-        const ConeEval e = cone_eval<false>(v, act ? in.lc : 0.0, mu, cm, act, dmax, so2);
+        const bool act = con_act(ck.cm, k);
+        const double v = con_value(zb, ck.arow, ck.brow);
+        const ConeEval e = cone_eval<false>(v, act ? in.lc : 0.0, mu, ck.cm, act, dmax, so2);
         Jacc += e.cost;
         viol = fmax(viol, e.viol);
         if constexpr (OPEN) stg(P.Lc, (wr_l & act) ? at(k) : at(P.N), in.lc);
@@ -556,31 +566,36 @@ struct Solver {
     const double t_zr = ldg(P.Zref, at(kref + kt));
     const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
     double t_z = 0.0, t_lc = 0.0;
+    ConK t_ck;
     if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
-    if constexpr (CONES) t_lc = ldg(P.Lc, at(kt));
+    if constexpr (CONES) {
+      t_lc = ldg(P.Lc, at(kt));
+      con_load(kt, t_ck);
+    }
 
     // software pipeline: operands of knot k+PD are requested right after knot k is consumed.
     // The main loop body is one basic block (PD stages, PD clamped loads).
-    constexpr int PD = OPEN ? ALTRO_PD_OPEN : ALTRO_PD_CLOSED;
+    constexpr int PD = CONES ? 2 : (OPEN ? ALTRO_PD_OPEN : ALTRO_PD_CLOSED);  // cone tables cost registers
     KnotIn ring[PD];
+    ConK cring[PD];
     sfor<0, PD>([&](auto u) {
       constexpr int U = decltype(u)::value;
-      load(imin(U, N - 2), ring[U]);
+      load(imin(U, N - 2), ring[U], cring[U]);
     });
     const int ngroups = (N - 1) / PD;
     int k = 0;
     for (int g = 0; g < ngroups; ++g, k += PD) {
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        stage(k + U, ring[U]);
-        load(imin(k + U + PD, N - 2), ring[U]);
+        stage(k + U, ring[U], cring[U]);
+        load(imin(k + U + PD, N - 2), ring[U], cring[U]);
       });
     }
     {  // remaining (N-1) % PD stage knots
       const int rem = (N - 1) - k;
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        if (U < rem) stage(k + U, ring[U]);
+        if (U < rem) stage(k + U, ring[U], cring[U]);
       });
     }
     {  // terminal knot: state only
@@ -590,9 +605,9 @@ struct Solver {
       else stg(P.Z, zd + at(kt), zb);
       Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
       if constexpr (CONES) {
-        const bool act = con_act(cm, kt);
-        const double v = con_value(zb, arow, brow);
-        const ConeEval e = cone_eval<false>(v, act ? t_lc : 0.0, mu, cm, act, dmax, so2);
+        const bool act = con_act(t_ck.cm, kt);
+        const double v = con_value(zb, t_ck.arow, t_ck.brow);
+        const ConeEval e = cone_eval<false>(v, act ? t_lc : 0.0, mu, t_ck.cm, act, dmax, so2);
         Jacc += e.cost;
         viol = fmax(viol, e.viol);
       }
@@ -668,19 +683,14 @@ struct Solver {
     });
     const bool live = is_x | is_u;
     const double lm = is_x ? P.o.max_state_value : P.o.max_control_value;
-    ConMeta cm{};
-    double arow[NZ], brow = 0.0;
-    if constexpr (CONES) {
-      cm = con_meta();
-      con_row(arow, brow);
-    }
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
-    constexpr int UN = ALTRO_UN;
+    constexpr int UN = CONES ? 2 : ALTRO_UN;  // cone tables cost registers
     const int nch = (N + UN - 1) / UN;
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * UN;
       double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN], lcq[UN];
+      ConK ckq[UN];
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = imin(k0 + Q, N - 1);
@@ -690,7 +700,10 @@ struct Solver {
         lhi[Q] = ldg(P.Lb, lb_at(k, 0));
         llo[Q] = ldg(P.Lb, lb_at(k, 1));
         lcq[Q] = 0.0;
-        if constexpr (CONES) lcq[Q] = ldg(P.Lc, at(k));
+        if constexpr (CONES) {
+          lcq[Q] = ldg(P.Lc, at(k));
+          con_load(k, ckq[Q]);
+        }
       });
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
@@ -706,15 +719,15 @@ struct Solver {
         double cv0 = 0.0, cdv = 0.0;
         bool cact = false;
         if constexpr (CONES) {
-          cact = con_act(cm, k) & valid;
-          cv0 = con_value(on ? z[Q] : 0.0, arow, brow);
-          cdv = con_value(on ? zz1[Q] : 0.0, arow, brow) - cv0;
+          cact = con_act(ckq[Q].cm, k) & valid;
+          cv0 = con_value(on ? z[Q] : 0.0, ckq[Q].arow, ckq[Q].brow);
+          cdv = con_value(on ? zz1[Q] : 0.0, ckq[Q].arow, ckq[Q].brow) - cv0;
         }
         sfor<0, NA>([&](auto t) {
           constexpr int Tt = decltype(t)::value;
           const double zb = on ? __builtin_fma(a[Tt], dz, z[Q]) : 0.0;
           if constexpr (CONES) {
-            const ConeEval e = cone_eval<false>(__builtin_fma(a[Tt], cdv, cv0), cact ? lcq[Q] : 0.0, mu, cm, cact, dmax, so2);
+            const ConeEval e = cone_eval<false>(__builtin_fma(a[Tt], cdv, cv0), cact ? lcq[Q] : 0.0, mu, ckq[Q].cm, cact, dmax, so2);
             Jacc[Tt] += e.cost;
             viol[Tt] = fmax(viol[Tt], e.viol);
           }
@@ -799,21 +812,19 @@ struct Solver {
       g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
     });
     const int N = P.N;
-    // generic constraint rows: row j and column j of Acon stay in registers for the pass
-    ConMeta cm{};
-    double arow[NZ], brow = 0.0, acol[16];
-    if constexpr (CONES) {
-      cm = con_meta();
-      con_row(arow, brow);
-      con_col(acol);
-    }
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
-    // conic AL expansion at one knot: gradient A'g added to qz, Hessian A' M A added to hh
+    // conic AL expansion at one knot: gradient A'g added to qz, Hessian A' M A added to hh.
+    // Row j and column j of the knot's constraint table are loaded here (L2-resident, shared by
+    // every instance).
     auto cone_expand = [&](int k, double z, double lam, double& qz, double (&hh)[NZ]) {
-      const bool act = con_act(cm, k);
-      const double v = con_value(z, arow, brow);
-      const ConeEval e = cone_eval<true>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
+      ConK ck;
+      double acol[16];
+      con_load(k, ck);
+      con_col(k, acol);
+      const bool act = con_act(ck.cm, k);
+      const double v = con_value(z, ck.arow, ck.brow);
+      const ConeEval e = cone_eval<true>(v, act ? lam : 0.0, mu, ck.cm, act, dmax, so2);
       double a4[4] = {0.0, 0.0, 0.0, 0.0};
       BlkCommon::RS16(a4, e.g, acol);
       qz += (a4[0] + a4[1]) + (a4[2] + a4[3]);
@@ -1007,16 +1018,16 @@ struct Solver {
       stg(P.Lb, (upd & on & lc.has_lo) ? lb_at(k, 1) : trash_l(1), nlo);
     }
     if constexpr (CONES) {  // dual_update! of the generic rows: eq / ineq clamp, SOC projection
-      const ConMeta cm = con_meta();
-      double arow[NZ], brow;
-      con_row(arow, brow);
       const bool so2 = P.o.soc_second_order != 0;
       for (int k = 0; k < P.N; ++k) {
+        ConK ck;
+        con_load(k, ck);
+        const ConMeta& cm = ck.cm;
         const bool live = (k < P.N - 1) ? (is_x | is_u) : is_x;
         const double z = ldg(P.Z, zs + at(k));
         const double lam = ldg(P.Lc, at(k));
         const bool act = con_act(cm, k);
-        const double v = con_value(live ? z : 0.0, arow, brow);
+        const double v = con_value(live ? z : 0.0, ck.arow, ck.brow);
         const ConeEval e = cone_eval<false>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
         const bool row_on = act & ((cm.type == CT_SOC) ? (cm.pos < cm.p) : (cm.type != CT_NONE));
         stg(P.Lc, (upd & row_on) ? at(k) : at(P.N), e.lam_new);

@@ -132,11 +132,11 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qdiag, cons
  *   BOX:    zmin, zmax of length n+m (+-inf = absent)
  *   LINEAR: A [p][n+m] ROW-major, b [p]; value A z + b {= 0 | <= 0}
  *   SOC:    A, b as above; value v = A z + b with ||v[0..p-2]|| <= v[p-1]
- *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67) -- not
- *                  built yet in the HIP library (ALTRO_ERR_UNSUPPORTED)
- * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; the
- * LINEAR / SOC rows of a knot fit 4 quads of 4 rows (an SOC of dimension 2..4 takes one quad,
- * p linear rows take ceil(p/4)). */
+ *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67)
+ * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; at most
+ * 16 LINEAR / SOC rows are active at any one knot (a cone of dimension 2..4 takes the first lanes
+ * of an aligned group of 4, linear rows take any free lane; constraints with disjoint knot
+ * ranges share lanes); constraints are added before the first solve. */
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first,
                                    int32_t k_last, int32_t p, const double* A, const double* b,
                                    const double* zmin, const double* zmax, int32_t per_knot,

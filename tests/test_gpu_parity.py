@@ -287,6 +287,59 @@ def test_rocket_mpc_steps_with_cones_match_oracle(oracle):
             check_against_oracle(st, X, U, b, orcs[b], so)
 
 
+def test_grasp_cold_solve_matches_oracle_and_reference_fixture(oracle):
+    """Grasp optimisation (grasp_problem.jl:1-107): per-knot-varying torque-balance equality,
+    normal-force inequality and two friction second-order cones, plus the goal at the last knot
+    (which shares constraint-row lanes with the stage constraints).  Checked against the oracle
+    AND directly against the trajectory the reference stored (grasp_ref_traj.jld2)."""
+    from test_oracle_cones import load_grasp_fixture
+    y, z, F1, F2, theta, p1 = load_grasp_fixture()
+    gp = P.gen_grasp_problem(N=31, tf=3.0)
+    opts = dict(cost_tolerance=1e-8, cost_tolerance_intermediate=1e-7, constraint_tolerance=1e-7, penalty_initial=1.0,
+                penalty_scaling=10.0, iterations=5000, iterations_outer=60, iterations_inner=300,
+                gradient_tolerance=1e-5, gradient_tolerance_intermediate=1e-5)
+    B = 5
+    rng = np.random.default_rng(5)
+    x0 = np.tile(gp.x0, (B, 1))
+    x0[1:, 1:3] += 0.2 * rng.standard_normal((B - 1, 2))      # instance 0 is the reference's problem
+    sv = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0), altro.SolverOptions(**opts))
+    altro.solve(sv)
+    st = altro.stats(sv)
+    X, U = altro.states(sv), altro.controls(sv)
+    for b in range(B):
+        o = rocket_oracle(oracle, gp, x0[b], opts)
+        so = o.solve()
+        assert so.status == 1
+        check_against_oracle(st, X, U, b, o, so)
+        for ci in range(len(gp.constraints)):
+            lam_o = o.duals(o.con_ids[ci])
+            lam_g = altro.get_duals(sv, ci)[b].reshape(-1)
+            assert np.abs(lam_g - lam_o).max() <= RTOL * max(1.0, np.abs(lam_o).max())
+    # the reference's stored solver output
+    assert np.abs(X[0, :, 1] - y).max() < 1e-6 and np.abs(X[0, :, 2] - z).max() < 1e-6
+    assert np.abs(U[0, :, 1:3] - F1).max() < 1e-6 and np.abs(U[0, :, 4:6] - F2).max() < 1e-6
+
+
+def test_update_constraint_data_is_seen_by_the_next_solve(oracle):
+    """grasp_mpc_helpers.jl:46-55 mutates the per-knot constraint matrices in place between
+    solves; altro_batch_update_constraint_data is that mutation."""
+    gp = P.gen_grasp_problem(N=21, tf=2.0)
+    gp2 = P.gen_grasp_problem(N=21, tf=2.0, mu=0.3, f_max=2.5)
+    opts = dict(cost_tolerance_intermediate=1e-5, constraint_tolerance=1e-5, penalty_initial=1.0, penalty_scaling=10.0)
+    x0 = np.tile(gp.x0, (3, 1))
+    sv = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0), altro.SolverOptions(**opts))
+    altro.solve(sv)
+    for ci, c in enumerate(gp2.constraints):
+        altro.update_constraint_data(sv, ci, c.A, c.b)
+    altro.initial_controls(sv, np.tile(gp.U0, (3, 1, 1)))
+    altro.set_options(sv, reset_duals=1)
+    altro.solve(sv)
+    o = rocket_oracle(oracle, gp2, gp.x0, opts)
+    so = o.solve()
+    st = altro.stats(sv)
+    check_against_oracle(st, altro.states(sv), altro.controls(sv), 1, o, so)
+
+
 def test_error_paths():
     pb = altro.problems.gen_random_linear_batch(2, n=5, m=2, N=9, steps=1)
     with pytest.raises(altro.AltroError) as e:
