@@ -29,9 +29,9 @@ EXPORTS = [
     "altro_batch_set_options", "altro_batch_solve", "altro_batch_solve_async",
     "altro_batch_synchronize", "altro_batch_get_states", "altro_batch_get_controls",
     "altro_batch_get_duals", "altro_batch_set_duals", "altro_batch_get_stats",
-    "altro_batch_last_solve_ms", "altro_batch_timing_reset", "altro_batch_timing_get",
+    "altro_batch_get_alpha_trace", "altro_batch_get_gains", "altro_batch_last_solve_ms", "altro_batch_timing_reset", "altro_batch_timing_get",
     "altro_batch_get_work_counters", "altro_batch_get_wave_cycles", "altro_batch_get_solve_counters", "altro_mpc_run_async",
-    "altro_mpc_set_track", "altro_mpc_set_noise",
+    "altro_mpc_set_noise_model", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
 ]
 """every symbol include/altro_batch.h declares"""
@@ -113,6 +113,8 @@ def lib():
     L.altro_batch_get_duals.argtypes = [H, C.c_int32, dp]
     L.altro_batch_set_duals.argtypes = [H, C.c_int32, dp]
     L.altro_batch_get_stats.argtypes = [H, ip, ip, ip, dp, dp, dp, dp]
+    L.altro_batch_get_alpha_trace.argtypes = [H, dp]
+    L.altro_batch_get_gains.argtypes = [H, dp, dp]
     L.altro_batch_last_solve_ms.argtypes = [H, C.POINTER(C.c_float)]
     L.altro_batch_timing_reset.argtypes = [H]
     L.altro_batch_timing_get.argtypes = [H, C.POINTER(C.c_float), C.c_int32, ip]
@@ -121,6 +123,7 @@ def lib():
     i64 = C.POINTER(C.c_int64)
     L.altro_batch_get_solve_counters.argtypes = [H, i64, i64, i64]
     L.altro_mpc_run_async.argtypes = [H, C.c_int32, C.c_int32]
+    L.altro_mpc_set_noise_model.argtypes = [H, C.c_int32, dp, ip]
     L.altro_mpc_set_track.argtypes = [H, dp, dp, C.c_int32]
     L.altro_mpc_set_noise.argtypes = [H, dp, C.c_int32]
     L.altro_mpc_step_async.argtypes = [H, C.c_int32]

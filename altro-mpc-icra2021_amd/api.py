@@ -371,3 +371,18 @@ def update_constraint_data(solver, con, A=None, b=None):
     """In-place mutation of a constraint's (per-knot) data: grasp_mpc_helpers.jl:46-55."""
     solver._chk(solver._L.altro_batch_update_constraint_data(
         solver.h, solver.con_ids[con], _p(_c(A)) if A is not None else None, _p(_c(b)) if b is not None else None))
+
+
+def alpha_trace(solver):
+    """Accepted line-search step of the first TRACE_LEN iLQR iterations of the last solve."""
+    a = np.empty((solver.B, _lib.TRACE_LEN))
+    solver._chk(solver._L.altro_batch_get_alpha_trace(solver.h, _p(a)))
+    return a
+
+
+def gains(solver):
+    """(K, d) of the last backward pass: K (B, N-1, m, n), d (B, N-1, m)."""
+    K = np.empty((solver.B, solver.N - 1, solver.n, solver.m))
+    d = np.empty((solver.B, solver.N - 1, solver.m))
+    solver._chk(solver._L.altro_batch_get_gains(solver.h, _p(K), _p(d)))
+    return np.swapaxes(K, -1, -2).copy(), d

@@ -38,10 +38,12 @@ struct altro_handle {
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lb = nullptr, *mu = nullptr,
          *KD = nullptr;
-  double *noise = nullptr;
+  double *noise = nullptr, *noise_w = nullptr;
+  int* noise_grp = nullptr;
+  int noise_mode = 0;
   int* cur = nullptr;
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
-  double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr;
+  double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
   double* stage = nullptr;  // device staging buffer for host<->device layout conversion
   size_t stage_bytes = 0;
   int Nt = 0;    // knots held by Zref
@@ -286,7 +288,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
   p.kref = h->kref;
   p.first_step = first_step; p.nsteps = nsteps;
-  p.noise = h->noise;
+  p.noise = h->noise; p.noise_w = h->noise_w; p.noise_grp = h->noise_grp; p.noise_mode = h->noise_mode;
   p.box_k0 = h->box_k0; p.box_k1 = h->box_k1;
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
@@ -294,7 +296,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
-  p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace;
+  p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace; p.atrace = h->atrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
   p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
   p.o = h->o;
@@ -400,7 +402,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
   const size_t row = Bp * LW;
   // the kernels address every array with 32-bit element offsets
-  if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || (N - 1) * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
+  if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || N * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
     g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
     altro_batch_destroy(h);
     return ALTRO_ERR_UNSUPPORTED;
@@ -423,6 +425,15 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMalloc(&h->bcon, N * LW * sizeof(double)));
   CCHK(hipMalloc(&h->cmeta, N * LW * 4 * sizeof(int)));
   CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
+  CCHK(hipMalloc(&h->noise_w, LW * sizeof(double)));
+  CCHK(hipMalloc(&h->noise_grp, LW * sizeof(int)));
+  {
+    std::vector<double> w(LW, 0.01);  // 1 % of ||x0||_inf (random_linear_problem.jl:129)
+    std::vector<int> g(LW, 0);
+    CCHK(hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipStreamSynchronize(h->stream));
+  }
   CCHK(hipMalloc(&h->Lc, (N + 1) * row * sizeof(double)));
   h->Acon_h.assign(N * LW * LW, 0.0);
   h->bcon_h.assign(N * LW, 0.0);
@@ -434,7 +445,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMemsetAsync(h->Lc, 0, (N + 1) * row * sizeof(double), h->stream));
   CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
-  CCHK(hipMalloc(&h->KD, (N - 1) * Bp * m * LW * sizeof(double)));
+  CCHK(hipMalloc(&h->KD, N * Bp * m * LW * sizeof(double)));  // N-1 gain blocks + a trash slot
   CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
   CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
   CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
@@ -443,6 +454,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMalloc(&h->cmax, Bp * sizeof(double)));
   CCHK(hipMalloc(&h->Jtrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
   CCHK(hipMalloc(&h->ctrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+  CCHK(hipMalloc(&h->atrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+  CCHK(hipMemsetAsync(h->atrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
   CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
   CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
   CCHK(hipMalloc(&h->wave_cycles, Bp * 2 * sizeof(long long)));
@@ -459,7 +472,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
   CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->Lb, 0, (N + 1) * Bp * 2 * h->nbp * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->KD, 0, (N - 1) * Bp * m * LW * sizeof(double), h->stream));
+  CCHK(hipMemsetAsync(h->KD, 0, N * Bp * m * LW * sizeof(double), h->stream));
   CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
   CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));
   CCHK(hipMemsetAsync(h->iters_outer, 0, Bp * sizeof(int), h->stream));
@@ -488,9 +501,9 @@ int32_t altro_batch_destroy(altro_handle* h) {
   if (!h) return ALTRO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot, h->Acon, h->bcon, h->cmeta, h->Lc, h->lanebuf,
+  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot, h->Acon, h->bcon, h->cmeta, h->Lc, h->lanebuf, h->noise_w, h->noise_grp,
                   h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
-                  h->ctrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
+                  h->ctrace, h->atrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : h->hist) hipEventDestroy(e);
@@ -907,6 +920,32 @@ int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* ite
   return ALTRO_OK;
 }
 
+int32_t altro_batch_get_alpha_trace(altro_handle* h, double* alpha_trace) {
+  if (!h || !alpha_trace) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(alpha_trace, h->atrace, (size_t)h->d.batch * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+  return ALTRO_OK;
+}
+
+int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
+  if (!h || (!K && !d)) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t n = h->d.n, m = h->d.m, N = h->d.N, B = h->d.batch, Bp = h->Bp;
+  std::vector<double> kd((N - 1) * Bp * m * LW);
+  HIPCHK(h, hipMemcpy(kd.data(), h->KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost));
+  // device layout [k][instance][control a][lane]: state lane j holds K[a][j], control lane n+a holds d[a]
+  for (size_t b = 0; b < B; ++b)
+    for (size_t k = 0; k + 1 < N; ++k)
+      for (size_t a = 0; a < m; ++a) {
+        const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
+        if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
+        if (d) d[(b * (N - 1) + k) * m + a] = row[n + a];
+      }
+  return ALTRO_OK;
+}
+
 int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms) {
   if (!h || !ms) return ALTRO_ERR_INVALID_ARG;
   if (!h->timed) FAIL(h, ALTRO_ERR_STATE, "no solve has been launched");
@@ -1009,6 +1048,23 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
   HIPCHK(h, hipMalloc(&h->noise, cnt * sizeof(double)));
   HIPCHK(h, hipMemcpy(h->noise, noise, cnt * sizeof(double), hipMemcpyHostToDevice));
   h->noise_steps = steps;
+  return ALTRO_OK;
+}
+
+int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups) {
+  if (!h || !weights || (mode != 0 && mode != 1)) return ALTRO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> w(LW, 0.0);
+  std::vector<int> g(LW, 0);
+  for (int i = 0; i < h->d.n; ++i) {
+    w[i] = weights[i];
+    g[i] = groups ? groups[i] : 0;
+    if (g[i] != 0 && g[i] != 1) FAIL(h, ALTRO_ERR_INVALID_ARG, "noise groups are 0 or 1");
+  }
+  HIPCHK(h, hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->noise_mode = mode;
   return ALTRO_OK;
 }
 

@@ -84,6 +84,9 @@ struct SolveParams {
   double* x0;            // [Bp][16]
   const double* Zref;    // [Nt][Bp][16]
   const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
+  const double* noise_w; // [16] per-state noise weight
+  const int* noise_grp;  // [16] per-state norm group (0 or 1)
+  int noise_mode;        // 0: w_i * ||x||_inf (random_linear_problem.jl:129); 1: w_i * ||x[group_i]||_2 (simple_rocket.jl:65-71)
   double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
   int* cur;              // [Bp] which plane of Z is current
   double* Lb;            // [N+1][Bp][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
@@ -103,7 +106,7 @@ struct SolveParams {
                          // linear rows may use the quad's spare lanes)
   double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
   int ncrows;            // 0: no generic constraints
-  double* KD;            // [N-1][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX
+  double* KD;            // [N][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX; block N-1 = trash
   int* iters;
   int* iters_outer;
   int* status;
@@ -111,6 +114,7 @@ struct SolveParams {
   double* cmax;
   double* Jtrace;        // [Bp][ALTRO_TRACE_LEN]
   double* ctrace;        // [Bp][ALTRO_TRACE_LEN]
+  double* atrace;        // [Bp][ALTRO_TRACE_LEN] accepted line-search step (0 = search failed)
   long long* n_backward; // [Bp] work counters (accumulated across launches)
   long long* n_rollout;  // [Bp]
   long long* n_trials;   // [Bp] line-search trials evaluated by interpolation
@@ -507,7 +511,9 @@ struct Solver {
       in.lc = 0.0;
       if constexpr (CONES) {
         con_load(k, ck);
-        in.lc = ldg(P.Lc, at(shl ? imin(k + 1, ck.cm.k1) : k));
+        // shifted read stays inside the row's own knot range; lanes without a row (k1 = -1) read knot k
+        const int kc = (shl & (ck.cm.type != CT_NONE)) ? imax(imin(k + 1, ck.cm.k1), 0) : k;
+        in.lc = ldg(P.Lc, at(kc));
       }
     };
 
@@ -800,7 +806,7 @@ struct Solver {
   // Quu_reg is factored as L D L' (no square roots; pivots D_j > 0 is the same PD test as
   // Cholesky's).  RHO = false is the rho == 0 instantiation (every convex run).
   template <bool RHO>
-  __device__ void backward(double& dV1, double& dV2, bool& fail) {
+  __device__ void backward(double& dV1, double& dV2, bool& fail, bool live) {
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const double rho = RHO ? rs->rho : 0.0;
@@ -964,7 +970,7 @@ struct Solver {
       // gains out, every lane stores its own column: x lanes K[a][j], lanes >= NX d[a]
       sfor<0, NU>([&](auto a) {
         constexpr int A = decltype(a)::value;
-        stg(P.KD, kd_at(k, A), is_x ? kd[A] : dd_[A]);
+        stg(P.KD, kd_at(live ? k : N - 1, A), is_x ? kd[A] : dd_[A]);  // knot N-1 is the trash slot
       });
       // S = Qxx + Qux'K - rho K'K   (in place on h[0..NX-1]), then S = (S + S')/2
       if constexpr (RHO) {
@@ -1047,13 +1053,22 @@ struct Solver {
     double acc4[4] = {ldg(P.fvec, rowoff), 0.0, 0.0, 0.0};
     Blk<NX, NU>::GZ(acc4, z0, grow);
     const double xn = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-    const double nrm = row_max(is_x ? fabs(xn) : 0.0);
+    double nrm;
+    const double wgt = P.noise_w[j];
+    if (P.noise_mode == 0) {
+      nrm = row_max(is_x ? fabs(xn) : 0.0);
+    } else {
+      const int grp = P.noise_grp[j];
+      const double sq = is_x ? xn * xn : 0.0;
+      const double n0 = sqrt(row_sum(grp == 0 ? sq : 0.0)), n1 = sqrt(row_sum(grp == 1 ? sq : 0.0));
+      nrm = grp == 0 ? n0 : n1;
+    }
     double nz = 0.0;
     if (P.noise != nullptr && is_x && doit) {
       const int b = inst < P.B ? inst : P.B - 1;
       nz = P.noise[((size_t)step * P.B + b) * NX + j];
     }
-    const double x0n = is_x ? xn + nz * nrm / 100.0 : 0.0;
+    const double x0n = is_x ? xn + nz * nrm * wgt : 0.0;
     if (doit) stg(P.x0, rowoff, x0n);
   }
 
@@ -1166,8 +1181,8 @@ struct Solver {
           while (true) {
             bool fail;
             ALTRO_STAMP(long long ts = stamp();)
-            if (wave_any(rs->rho != 0.0)) backward<true>(dV1, dV2, fail);
-            else backward<false>(dV1, dV2, fail);
+            if (wave_any(rs->rho != 0.0)) backward<true>(dV1, dV2, fail, inner);
+            else backward<false>(dV1, dV2, fail, inner);
             ALTRO_STAMP(t_bw += stamp() - ts;)
             if (inner) rs->nbw += 1;
             fail = row_any(fail, lane) && inner;
@@ -1283,6 +1298,7 @@ struct Solver {
               if (it_total < ALTRO_TRACE_LEN && j == 0) {
                 P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + it_total] = Jn;
                 P.ctrace[(size_t)inst * ALTRO_TRACE_LEN + it_total] = cm_n;
+                P.atrace[(size_t)inst * ALTRO_TRACE_LEN + it_total] = alpha;
               }
               rs->iters = it_total + 1;
               rs->it += 1;

@@ -75,3 +75,30 @@ class BatchMPC:
         out = np.empty((s.B, s.n))
         s._chk(s._L.altro_batch_get_initial_state(s.h, api._p(out)))
         return out
+
+
+class TrackMPC:
+    """Device-resident MPC loop for any tracking problem: the solver is built on the first window
+    of (Xtrack, Utrack); `noise` are unit normals (steps, B, n).  noise_model: None for the
+    random-linear model (1 % of ||x0||_inf) or (weights, groups) for the two-group 2-norm model of
+    the rocket benchmark (simple_rocket.jl:65-71)."""
+
+    def __init__(self, prob, opts, Xtrack, Utrack, noise, noise_model=None, device=0):
+        self.solver = api.ALTROSolver(prob, opts, device)
+        s = self.solver
+        Xt, Ut = api._c(Xtrack), api._c(Utrack)
+        s._chk(s._L.altro_mpc_set_track(s.h, api._p(Xt), api._p(Ut), Xt.shape[1]))
+        nz = api._c(noise)
+        s._chk(s._L.altro_mpc_set_noise(s.h, api._p(nz), nz.shape[0]))
+        if noise_model is not None:
+            w = api._c(noise_model[0])
+            g = np.ascontiguousarray(noise_model[1], dtype=np.int32)
+            s._chk(s._L.altro_mpc_set_noise_model(s.h, 1, api._p(w), g.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.i = 0
+
+    initial_solve = BatchMPC.initial_solve
+    step_async = BatchMPC.step_async
+    run_async = BatchMPC.run_async
+    synchronize = BatchMPC.synchronize
+    step = BatchMPC.step
+    x0 = BatchMPC.x0

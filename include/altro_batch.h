@@ -179,6 +179,12 @@ int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lam
 int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* iterations_outer,
                               int32_t* status, double* cost, double* c_max, double* cost_trace,
                               double* cmax_trace);
+/* accepted line-search step of each of the first ALTRO_TRACE_LEN iLQR iterations of the last
+ * solve, [batch][ALTRO_TRACE_LEN] (0 = the search failed and the trajectory was kept) */
+int32_t altro_batch_get_alpha_trace(altro_handle* h, double* alpha_trace);
+/* feedback gains K [batch][N-1] blocks of m x n (column-major) and feedforward d [batch][N-1][m]
+ * left by the last backward pass of the last solve (backwardpass!, ilqr K/d; either may be NULL) */
+int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d);
 /* device time of the last solve launch sequence on the handle's stream, HIP events (ms) */
 int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms);
 /* Launch-duration history of the solve kernel (HIP events recorded on the handle's stream around
@@ -210,6 +216,11 @@ int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t ca
 int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double* Utrack, int32_t Nt);
 /* unit-normal samples for the 1 % plant noise (random_linear_problem.jl:129): [steps][batch][n] */
 int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps);
+/* Plant-noise model of the device-side MPC step: x0_i += noise_i * weights[i] * norm, with
+ *   mode 0: norm = ||x0||_inf over all states (random_linear_problem.jl:129; default, weights 1/100)
+ *   mode 1: norm = ||x0[group_i]||_2, groups[i] in {0,1} (simple_rocket.jl:65-71: positions with
+ *           weight 1/1000, velocities with weight 1/100) */
+int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups);
 /* One MPC step i (0-based), enqueued on the handle's stream, in the reference's order
  * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
  * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */

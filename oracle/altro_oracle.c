@@ -878,6 +878,8 @@ void orc_shift_fill(orc_solver* s, int primal, int dual) {
 /* ---------------------------------------------------------------- accessors (P13) */
 const double* orc_states(const orc_solver* s) { return s->X; }
 const double* orc_controls(const orc_solver* s) { return s->U; }
+const double* orc_gain_K(const orc_solver* s) { return s->K; }
+const double* orc_gain_d(const orc_solver* s) { return s->d; }
 const orc_stats* orc_get_stats(const orc_solver* s) { return &s->stats; }
 int orc_num_duals(const orc_solver* s, int con) { return s->con[con].nk * s->con[con].p; }
 const double* orc_duals(const orc_solver* s, int con) { return s->con[con].lam; }

@@ -135,6 +135,8 @@ void orc_solve(orc_solver* s);
 
 const double* orc_states(const orc_solver* s);    /* N*n */
 const double* orc_controls(const orc_solver* s);  /* (N-1)*m */
+const double* orc_gain_K(const orc_solver* s);    /* (N-1) blocks of m*n, column-major */
+const double* orc_gain_d(const orc_solver* s);    /* (N-1)*m */
 const orc_stats* orc_get_stats(const orc_solver* s);
 int orc_num_duals(const orc_solver* s, int con);
 const double* orc_duals(const orc_solver* s, int con);     /* [nk][p] */

@@ -79,6 +79,10 @@ def lib():
         L.orc_states.restype = dp
         L.orc_states.argtypes = [C.c_void_p]
         L.orc_controls.restype = dp
+        L.orc_gain_K.restype = dp
+        L.orc_gain_K.argtypes = [C.c_void_p]
+        L.orc_gain_d.restype = dp
+        L.orc_gain_d.argtypes = [C.c_void_p]
         L.orc_controls.argtypes = [C.c_void_p]
         L.orc_get_stats.restype = C.POINTER(Stats)
         L.orc_get_stats.argtypes = [C.c_void_p]
@@ -195,6 +199,12 @@ class OracleSolver:
 
     def controls(self):
         return np.ctypeslib.as_array(lib().orc_controls(self.h), shape=(self.N - 1, self.m)).copy()
+
+    def gains(self):
+        """(K, d) of the last backward pass: K (N-1, m, n), d (N-1, m)."""
+        K = np.ctypeslib.as_array(lib().orc_gain_K(self.h), shape=(self.N - 1, self.n, self.m)).copy()
+        d = np.ctypeslib.as_array(lib().orc_gain_d(self.h), shape=(self.N - 1, self.m)).copy()
+        return np.swapaxes(K, -1, -2).copy(), d
 
     def duals(self, con):
         k = lib().orc_num_duals(self.h, con)
