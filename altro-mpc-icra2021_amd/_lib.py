@@ -31,7 +31,7 @@ EXPORTS = [
     "altro_batch_get_duals", "altro_batch_set_duals", "altro_batch_get_stats",
     "altro_batch_get_alpha_trace", "altro_batch_get_gains", "altro_batch_last_solve_ms", "altro_batch_timing_reset", "altro_batch_timing_get",
     "altro_batch_get_work_counters", "altro_batch_get_wave_cycles", "altro_batch_get_solve_counters", "altro_mpc_run_async",
-    "altro_mpc_set_noise_model", "altro_mpc_set_track", "altro_mpc_set_noise",
+    "altro_mpc_set_noise_model", "altro_mpc_set_shift", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
 ]
 """every symbol include/altro_batch.h declares"""
@@ -124,6 +124,7 @@ def lib():
     L.altro_batch_get_solve_counters.argtypes = [H, i64, i64, i64]
     L.altro_mpc_run_async.argtypes = [H, C.c_int32, C.c_int32]
     L.altro_mpc_set_noise_model.argtypes = [H, C.c_int32, dp, ip]
+    L.altro_mpc_set_shift.argtypes = [H, C.c_int32]
     L.altro_mpc_set_track.argtypes = [H, dp, dp, C.c_int32]
     L.altro_mpc_set_noise.argtypes = [H, dp, C.c_int32]
     L.altro_mpc_step_async.argtypes = [H, C.c_int32]

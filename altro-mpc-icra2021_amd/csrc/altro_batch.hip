@@ -41,6 +41,7 @@ struct altro_handle {
   double *noise = nullptr, *noise_w = nullptr;
   int* noise_grp = nullptr;
   int noise_mode = 0;
+  int mpc_shift = 1;
   int* cur = nullptr;
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
@@ -280,7 +281,7 @@ __global__ void k_fill(double* p, double v, size_t nelem) {
 static inline dim3 grid_for(size_t threads, int block = 256) { return dim3((unsigned)((threads + block - 1) / block)); }
 
 static bool supported_dims(int n, int m) {
-  return (n == 12 && m == 4) || (n == 6 && m == 3) || (n == 6 && m == 6) || (n == 8 && m == 4);
+  return (n == 12 && m == 4) || (n == 6 && m == 3) || (n == 6 && m == 6) || (n == 8 && m == 4) || (n == 12 && m == 3);
 }
 
 static int launch_solve(altro_handle* h, int first_step, int nsteps) {
@@ -288,7 +289,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
   p.kref = h->kref;
   p.first_step = first_step; p.nsteps = nsteps;
-  p.noise = h->noise; p.noise_w = h->noise_w; p.noise_grp = h->noise_grp; p.noise_mode = h->noise_mode;
+  p.noise = h->noise; p.noise_w = h->noise_w; p.noise_grp = h->noise_grp; p.noise_mode = h->noise_mode; p.mpc_shift = h->mpc_shift;
   p.box_k0 = h->box_k0; p.box_k1 = h->box_k1;
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
@@ -312,6 +313,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps) {
   else if (n == 6 && m == 3) ALTRO_LAUNCH(6, 3);
   else if (n == 6 && m == 6) ALTRO_LAUNCH(6, 6);
   else if (n == 8 && m == 4) ALTRO_LAUNCH(8, 4);
+  else if (n == 12 && m == 3) ALTRO_LAUNCH(12, 3);
   else FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
 #undef ALTRO_LAUNCH
   HIPCHK(h, hipGetLastError());
@@ -373,7 +375,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   *out = nullptr;
   if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
   if (!supported_dims(dims->n, dims->m)) {
-    g_create_err = "unsupported (n, m): kernels are built for (12,4), (6,3), (6,6), (8,4)";
+    g_create_err = "unsupported (n, m): kernels are built for (12,4), (6,3), (6,6), (8,4), (12,3)";
     return ALTRO_ERR_UNSUPPORTED;
   }
   int ndev = 0;
@@ -1052,7 +1054,7 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
 }
 
 int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups) {
-  if (!h || !weights || (mode != 0 && mode != 1)) return ALTRO_ERR_INVALID_ARG;
+  if (!h || !weights || mode < 0 || mode > 2) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<double> w(LW, 0.0);
   std::vector<int> g(LW, 0);
@@ -1065,6 +1067,12 @@ int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* w
   HIPCHK(h, hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->noise_mode = mode;
+  return ALTRO_OK;
+}
+
+int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift) {
+  if (!h) return ALTRO_ERR_INVALID_ARG;
+  h->mpc_shift = shift ? 1 : 0;
   return ALTRO_OK;
 }
 

@@ -24,7 +24,7 @@ NX+a owns control column a, lanes >= NX+NU idle (carry zeros).
 """
 import sys
 
-SIZES = [(12, 4), (6, 3), (6, 6), (8, 4)]
+SIZES = [(12, 4), (6, 3), (6, 6), (8, 4), (12, 3)]
 
 DPP = "row_newbcast:{k} row_mask:0xf bank_mask:0xf"
 

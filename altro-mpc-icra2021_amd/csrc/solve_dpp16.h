@@ -86,7 +86,9 @@ struct SolveParams {
   const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
   const double* noise_w; // [16] per-state noise weight
   const int* noise_grp;  // [16] per-state norm group (0 or 1)
-  int noise_mode;        // 0: w_i * ||x||_inf (random_linear_problem.jl:129); 1: w_i * ||x[group_i]||_2 (simple_rocket.jl:65-71)
+  int noise_mode;        // 0: w_i * ||x||_inf (random_linear_problem.jl:129); 1: w_i * ||x[group_i]||_2
+                         // (simple_rocket.jl:65-71); 2: w_i (absolute, flexible_sat_mpc.jl:266)
+  int mpc_shift;         // 1: shift_fill primal + dual at every MPC step (default); 0: keep (flexible_sat_mpc.jl:275-276)
   double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
   int* cur;              // [Bp] which plane of Z is current
   double* Lb;            // [N+1][Bp][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
@@ -1057,6 +1059,8 @@ struct Solver {
     const double wgt = P.noise_w[j];
     if (P.noise_mode == 0) {
       nrm = row_max(is_x ? fabs(xn) : 0.0);
+    } else if (P.noise_mode == 2) {
+      nrm = 1.0;
     } else {
       const int grp = P.noise_grp[j];
       const double sq = is_x ? xn * xn : 0.0;
@@ -1125,7 +1129,7 @@ struct Solver {
               rs->outer = 0;
               rs->J = 0.0;
               rs->cmax = 0.0;
-              rs->shift = mpc ? 1 : 0;
+              rs->shift = (mpc && P.mpc_shift) ? 1 : 0;
               rs->phase = PH_OUTER_BEGIN;
             } else {
               rs->phase = PH_DONE;

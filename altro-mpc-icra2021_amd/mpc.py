@@ -80,20 +80,28 @@ class BatchMPC:
 class TrackMPC:
     """Device-resident MPC loop for any tracking problem: the solver is built on the first window
     of (Xtrack, Utrack); `noise` are unit normals (steps, B, n).  noise_model: None for the
-    random-linear model (1 % of ||x0||_inf) or (weights, groups) for the two-group 2-norm model of
-    the rocket benchmark (simple_rocket.jl:65-71)."""
+    random-linear model (1 % of ||x0||_inf), (weights, groups) for the two-group 2-norm model of
+    the rocket benchmark (simple_rocket.jl:65-71), or (weights,) for absolute noise
+    (flexible_sat_mpc.jl:266).  shift=False keeps the previous solution and duals as the warm
+    start instead of shifting them (flexible_sat_mpc.jl:275-276)."""
 
-    def __init__(self, prob, opts, Xtrack, Utrack, noise, noise_model=None, device=0):
+    def __init__(self, prob, opts, Xtrack, Utrack, noise, noise_model=None, device=0, shift=True):
         self.solver = api.ALTROSolver(prob, opts, device)
         s = self.solver
         Xt, Ut = api._c(Xtrack), api._c(Utrack)
         s._chk(s._L.altro_mpc_set_track(s.h, api._p(Xt), api._p(Ut), Xt.shape[1]))
+        api.set_initial_state(s, prob.x0)        # set_track starts from the track's first knot; the problem's x0 wins
         nz = api._c(noise)
         s._chk(s._L.altro_mpc_set_noise(s.h, api._p(nz), nz.shape[0]))
         if noise_model is not None:
             w = api._c(noise_model[0])
-            g = np.ascontiguousarray(noise_model[1], dtype=np.int32)
-            s._chk(s._L.altro_mpc_set_noise_model(s.h, 1, api._p(w), g.ctypes.data_as(C.POINTER(C.c_int32))))
+            if len(noise_model) > 1:
+                g = np.ascontiguousarray(noise_model[1], dtype=np.int32)
+                s._chk(s._L.altro_mpc_set_noise_model(s.h, 1, api._p(w), g.ctypes.data_as(C.POINTER(C.c_int32))))
+            else:
+                s._chk(s._L.altro_mpc_set_noise_model(s.h, 2, api._p(w), None))
+        if not shift:
+            s._chk(s._L.altro_mpc_set_shift(s.h, 0))
         self.i = 0
 
     initial_solve = BatchMPC.initial_solve

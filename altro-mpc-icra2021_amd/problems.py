@@ -81,6 +81,59 @@ def gen_random_linear_batch(batch, n=12, m=4, N=50, steps=100, dt=0.1, seed=1, f
 
 
 # ---------------------------------------------------------------------------------------------
+# flexible spacecraft: reference benchmarks/flexible_satellite/flexible_sat_mpc.jl
+FLEXSAT_OPTS = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-4,
+                    penalty_initial=100.0, penalty_scaling=100.0)
+"""set_options! of flexible_sat_mpc.jl:250-257 at tol = 1e-4 (reset_duals stays at its default, true)"""
+
+
+def flexsat_model(dt=0.5):
+    """Rigid hub with reaction wheels and three flexible modes, x = [MRP(3); omega(3); eta(3);
+    eta_dot(3)], u = wheel torques (generate_AB, flexible_sat_mpc.jl:72-130), discretised with a
+    zero-order hold by one matrix exponential of [[A, B], [0, 0]] dt (c2d, :59-70)."""
+    from scipy.linalg import expm
+    inertia = np.diag([1.0, 2.0, 3.0])
+    coupling = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-0.7, 0.1, 0.1]])      # angular momentum coupling
+    wn = 2.0 * np.pi * np.array([0.05, 0.2, 0.125])                               # modal frequencies
+    zeta = np.full(3, 1e-3)
+    Kmod, Cmod = np.diag(wn ** 2), np.diag(2.0 * zeta * wn)
+    T = np.linalg.inv(inertia - coupling.T @ coupling)
+    Ac = np.zeros((12, 12))
+    Ac[0:3, 3:6] = 0.25 * np.eye(3)                      # MRP kinematics about the origin
+    Ac[3:6, 6:9] = T @ coupling.T @ Kmod
+    Ac[3:6, 9:12] = T @ coupling.T @ Cmod
+    Ac[6:9, 9:12] = np.eye(3)
+    Ac[9:12, 6:9] = -Kmod - coupling @ T @ coupling.T @ Kmod
+    Ac[9:12, 9:12] = -Cmod - coupling @ T @ coupling.T @ Cmod
+    Bc = np.zeros((12, 3))
+    Bc[3:6] = -T
+    Bc[9:12] = coupling @ T
+    M = np.zeros((15, 15))
+    M[:12, :12], M[:12, 12:] = Ac * dt, Bc * dt
+    E = expm(M)
+    return E[:12, :12].copy(), E[:12, 12:].copy()
+
+
+def gen_flexsat_batch(batch, steps=45, N=80, seed=2, first_instance=0):
+    """run_flexsat_mpc (:133-296) for a batch: every instance has the same plant, its own initial
+    attitude error (the reference starts from MRP = 0.1 on each axis; instance 0 does too) and its
+    own noise stream.  LQR to the origin = tracking an all-zero trajectory; |u| <= 0.01; cost dt 0.1.
+    `noise` are unit normals: the plant adds 0.0002 * noise (:266), absolute.  Returns (batch, x0)."""
+    A, Bm = flexsat_model()
+    Nt = N + steps + 1
+    x0 = np.zeros((batch, 12))
+    noise = np.empty((steps, batch, 12))
+    for b in range(batch):
+        rng = instance_rng(seed, first_instance + b)
+        x0[b, :3] = 0.1 if first_instance + b == 0 else 0.1 * (1.0 + 0.3 * rng.standard_normal(3))
+        noise[:, b] = rng.standard_normal((steps, 12))
+    pb = RandomLinearBatch(n=12, m=3, N=N, dt=0.1, A=np.tile(A, (batch, 1, 1)), Bm=np.tile(Bm, (batch, 1, 1)),
+                           Xtrack=np.zeros((batch, Nt, 12)), Utrack=np.zeros((batch, Nt - 1, 3)), noise=noise,
+                           u_bnd=0.01)
+    return pb, x0
+
+
+# ---------------------------------------------------------------------------------------------
 # rocket landing (BASELINE config 3): reference benchmarks/rocket_landing/rocket_landing_problem.jl
 BOX, LINEAR, SOC = 0, 1, 2
 EQ, INEQ = 0, 1

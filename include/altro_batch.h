@@ -219,8 +219,13 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
 /* Plant-noise model of the device-side MPC step: x0_i += noise_i * weights[i] * norm, with
  *   mode 0: norm = ||x0||_inf over all states (random_linear_problem.jl:129; default, weights 1/100)
  *   mode 1: norm = ||x0[group_i]||_2, groups[i] in {0,1} (simple_rocket.jl:65-71: positions with
- *           weight 1/1000, velocities with weight 1/100) */
+ *           weight 1/1000, velocities with weight 1/100)
+ *   mode 2: norm = 1, absolute noise (flexible_sat_mpc.jl:266: 0.0002 * randn) */
 int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups);
+/* shift = 0: the device MPC step keeps the previous solution and duals as the warm start instead of
+ * shifting them by one knot (flexible_sat_mpc.jl:275-276 leaves both shift_fill! calls commented
+ * out); default 1 */
+int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift);
 /* One MPC step i (0-based), enqueued on the handle's stream, in the reference's order
  * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
  * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */

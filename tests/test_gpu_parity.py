@@ -433,6 +433,39 @@ def test_rocket_mpc_horizon_100_reference_config(oracle):
     assert strict >= B and ties >= 1     # both kinds of case were exercised
 
 
+def test_flexible_satellite_mpc_matches_oracle(oracle):
+    """Flexible spacecraft LQ MPC (flexible_sat_mpc.jl:133-296; n = 12, m = 3, N = 80, |u| <= 0.01):
+    cold solve, then the reference's loop on the device: x0 <- A x0 + B u_1 + 0.0002 randn, solve
+    again from the unshifted previous solution with the duals reset (:259-277)."""
+    B, S = 6, 6
+    pb, x0 = P.gen_flexsat_batch(B, steps=S)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.x0 = x0.copy()
+    mp = altro.mpc.TrackMPC(prob, altro.SolverOptions(**P.FLEXSAT_OPTS), pb.Xtrack, pb.Utrack, pb.noise,
+                            noise_model=(np.full(12, 2e-4),), shift=False)
+    mp.initial_solve()
+    orcs = []
+    st, X, U = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver)
+    for b in range(B):
+        o = make_oracle(oracle, pb, b, opts=P.FLEXSAT_OPTS)
+        o.set_initial_state(x0[b])
+        check_against_oracle(st, X, U, b, o, o.solve())
+        orcs.append(o)
+    sat = 0
+    for i in range(S):
+        mp.step(i)
+        st, X, U, x0g = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()
+        for b in range(B):
+            xn = orcs[b].plant_step() + 2e-4 * pb.noise[i, b]
+            assert np.abs(x0g[b] - xn).max() <= 1e-12
+            orcs[b].set_initial_state(xn)
+            so = orcs[b].solve()
+            assert so.status == 1
+            check_against_oracle(st, X, U, b, orcs[b], so)
+            sat += int((np.abs(U[b]) > pb.u_bnd - 1e-4).sum())
+    assert sat > 100            # the torque bound is active throughout
+
+
 def test_grasp_cold_solve_matches_oracle_and_reference_fixture(oracle):
     """Grasp optimisation (grasp_problem.jl:1-107): per-knot-varying torque-balance equality,
     normal-force inequality and two friction second-order cones, plus the goal at the last knot

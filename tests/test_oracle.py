@@ -147,3 +147,50 @@ def test_shift_fill_semantics(oracle):
     ls = s.duals(0).reshape(5, 12)
     l0 = lam.reshape(5, 12)
     assert np.array_equal(ls[:4], l0[1:]) and np.array_equal(ls[4], l0[4])
+
+
+def test_flexible_satellite_matches_independent_convex_solve(oracle):
+    """Flexible spacecraft (flexible_sat_mpc.jl:133-296): N = 80, torque bound
+    0.01 saturated over most of the horizon, lightly damped modes (|eig(A)| = 1).  The reference
+    validates ALTRO against OSQP on this problem (:176-232); here the oracle's converged solve is
+    held against the bounded-least-squares solution of the condensed problem."""
+    pb, x0 = problems.gen_flexsat_batch(2, steps=2)
+    assert abs(np.abs(np.linalg.eigvals(pb.A[0])).max() - 1.0) < 1e-9
+    tight = dict(problems.FLEXSAT_OPTS, cost_tolerance=1e-12, cost_tolerance_intermediate=1e-12,
+                 constraint_tolerance=1e-10, gradient_tolerance=1e-8, gradient_tolerance_intermediate=1e-8,
+                 penalty_scaling=10.0, iterations_outer=40, iterations=3000)
+    for b in range(2):
+        s = make_oracle(oracle, pb, b, opts=tight)
+        s.set_initial_state(x0[b])
+        st = s.solve()
+        assert st.status == 1, (st.status, st.iterations, st.c_max)
+        Xr, Ur = pb.window(0)
+        X, U, res = condensed_qp(pb.A[b], pb.Bm[b], x0[b], Xr[b], Ur[b], np.full(12, pb.Qk), np.full(3, pb.Rk),
+                                 np.full(12, pb.Qfk), pb.dt, pb.u_bnd)
+        assert res.status >= 1
+        assert (np.abs(U) > pb.u_bnd - 1e-9).sum() >= 20         # the bound shapes the solution
+        assert np.abs(s.controls() - U).max() < 1e-6
+        assert np.abs(s.states() - X).max() < 1e-6
+
+
+def test_flexible_satellite_mpc_loop_warm_starts(oracle):
+    """The reference's MPC loop for this problem (:259-277): x0 <- A x0 + B u_1 + 0.0002 randn,
+    solve! again from the previous solution WITHOUT shifting (the shift_fill! calls are commented
+    out), reset_duals left at true.  Every solve succeeds in a handful of iterations and the
+    closed loop drives the attitude error down against the torque limit."""
+    pb, x0 = problems.gen_flexsat_batch(1, steps=10)
+    s = make_oracle(oracle, pb, 0, opts=problems.FLEXSAT_OPTS)
+    s.set_initial_state(x0[0])
+    first = s.solve()
+    assert first.status == 1
+    its, err = [], [np.abs(x0[0, :3]).max()]
+    for i in range(10):
+        xn = s.plant_step() + 2e-4 * pb.noise[i, 0]
+        s.set_initial_state(xn)
+        st = s.solve()
+        assert st.status == 1
+        assert np.abs(s.controls()).max() <= pb.u_bnd + 1e-4
+        its.append(st.iterations)
+        err.append(np.abs(xn[:3]).max())
+    assert max(its) <= 20, its
+    assert err[-1] < err[0]
