@@ -15,6 +15,7 @@
 
 #include "../../include/altro_batch.h"
 #include "solve_dpp16.h"
+#include "wide_backend.h"
 
 using altro::IPW;
 using altro::LW;
@@ -22,6 +23,7 @@ using altro::LW;
 static thread_local std::string g_create_err;
 
 struct altro_handle {
+  altro_wide::WideBackend* wide = nullptr;  // set: this handle runs on the one-wave-per-instance kernel
   altro_dims d{};
   altro_opts o{};
   int device = 0;
@@ -89,6 +91,16 @@ struct altro_handle {
   do {                     \
     (h)->err = (msg);      \
     return (code);         \
+  } while (0)
+
+// forward an entry point to the wide backend when the handle runs on it
+#define WIDE_FWD(h, call)                           \
+  do {                                              \
+    if ((h) && (h)->wide) {                         \
+      const int rc_ = (h)->wide->call;              \
+      if (rc_) (h)->err = (h)->wide->err;           \
+      return rc_;                                   \
+    }                                               \
   } while (0)
 
 static int ensure_stage(altro_handle* h, size_t bytes) {
@@ -374,8 +386,12 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   if (!dims || !out) { g_create_err = "null argument"; return ALTRO_ERR_INVALID_ARG; }
   *out = nullptr;
   if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
-  if (!supported_dims(dims->n, dims->m)) {
-    g_create_err = "unsupported (n, m): kernels are built for (12,4), (6,3), (6,6), (8,4), (12,3)";
+  // (n, m) of the 16-lane kernel set run there; everything else up to n <= 64, m <= 32 runs on the
+  // one-wave-per-instance MFMA kernel (ALTRO_FORCE_WIDE=1 sends every size there: used by the tests)
+  const char* fw = getenv("ALTRO_FORCE_WIDE");
+  const bool use_wide = !supported_dims(dims->n, dims->m) || (fw && fw[0] == '1');
+  if (use_wide && !altro_wide::WideBackend::supports(dims->n, dims->m)) {
+    g_create_err = "unsupported (n, m): the wide kernel holds n <= 64, m <= 32";
     return ALTRO_ERR_UNSUPPORTED;
   }
   int ndev = 0;
@@ -385,6 +401,27 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     return ALTRO_ERR_HIP;
   }
   if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return ALTRO_ERR_INVALID_ARG; }
+  if (use_wide) {
+    altro_handle* hw = new (std::nothrow) altro_handle();
+    altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
+    if (!hw || !wb) { g_create_err = "out of host memory"; delete hw; delete wb; return ALTRO_ERR_INVALID_ARG; }
+    altro_opts o0;
+    if (opts) o0 = *opts; else altro_default_opts(&o0);
+    hw->d = *dims;
+    hw->o = o0;
+    hw->device = device;
+    const int rc = wb->create(dims, &o0, device);
+    if (rc) {
+      g_create_err = wb->err;
+      wb->destroy();
+      delete wb;
+      delete hw;
+      return rc;
+    }
+    hw->wide = wb;
+    *out = hw;
+    return ALTRO_OK;
+  }
   altro_handle* h = new (std::nothrow) altro_handle();
   if (!h) { g_create_err = "out of host memory"; return ALTRO_ERR_INVALID_ARG; }
   h->d = *dims;
@@ -501,6 +538,12 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
 
 int32_t altro_batch_destroy(altro_handle* h) {
   if (!h) return ALTRO_OK;
+  if (h->wide) {
+    h->wide->destroy();
+    delete h->wide;
+    delete h;
+    return ALTRO_OK;
+  }
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot, h->Acon, h->bcon, h->cmeta, h->Lc, h->lanebuf, h->noise_w, h->noise_grp,
@@ -518,6 +561,7 @@ int32_t altro_batch_destroy(altro_handle* h) {
 
 int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
                                  int32_t per_knot, int32_t per_instance) {
+  WIDE_FWD(h, set_dynamics(A, B, f, per_knot, per_instance));
   if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
   if (per_knot) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot (LTV) dynamics are not built yet");
   HIPCHK(h, hipSetDevice(h->device));
@@ -540,6 +584,7 @@ int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double*
 }
 
 int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const double* Rd, const double* Qfd, double dt) {
+  WIDE_FWD(h, set_tracking_cost(Qd, Rd, Qfd, dt));
   if (!h || !Qd || !Rd || !Qfd || !(dt > 0)) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const int n = h->d.n, m = h->d.m;
@@ -632,6 +677,7 @@ static int pack_constraints(altro_handle* h) {
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first, int32_t k_last,
                                    int32_t p, const double* A, const double* b, const double* zmin, const double* zmax,
                                    int32_t per_knot, int32_t* con_id) {
+  WIDE_FWD(h, add_constraint(kind, sense, k_first, k_last, p, A, b, zmin, zmax, per_knot, con_id));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   if (k_first < 0 || k_last >= h->d.N || k_last < k_first) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad knot range");
   HIPCHK(h, hipSetDevice(h->device));
@@ -685,6 +731,7 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
 }
 
 int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A, const double* b) {
+  WIDE_FWD(h, update_constraint_data(con_id, A, b));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const int nz = h->d.n + h->d.m;
@@ -703,6 +750,7 @@ int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, cons
 }
 
 int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
+  WIDE_FWD(h, set_initial_state(x0));
   if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t cnt = (size_t)h->d.batch * h->d.n;
@@ -717,6 +765,7 @@ int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
 }
 
 int32_t altro_batch_get_initial_state(altro_handle* h, double* x0) {
+  WIDE_FWD(h, get_initial_state(x0));
   if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t cnt = (size_t)h->d.batch * h->d.n;
@@ -754,12 +803,14 @@ static int set_ref_common(altro_handle* h, const double* Xref, const double* Ure
 }
 
 int32_t altro_batch_set_reference(altro_handle* h, const double* Xref, const double* Uref) {
+  WIDE_FWD(h, set_reference(Xref, Uref));
   if (!h || !Xref || !Uref) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   return set_ref_common(h, Xref, Uref, h->d.N);
 }
 
 int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, const double* U) {
+  WIDE_FWD(h, set_initial_trajectory(X, U));
   if (!h || !U) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t B = h->d.batch, N = h->d.N, n = h->d.n, m = h->d.m;
@@ -777,6 +828,7 @@ int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, con
 }
 
 int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
+  WIDE_FWD(h, shift_fill(primal, dual));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t plane = (size_t)h->d.N * h->Bp * LW;
@@ -788,6 +840,7 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
 }
 
 int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
+  if (h && h->wide && o) { h->wide->o = *o; h->o = *o; return ALTRO_OK; }
   if (!h || !o) return ALTRO_ERR_INVALID_ARG;
   h->o = *o;
   return ALTRO_OK;
@@ -821,11 +874,13 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
 }
 
 int32_t altro_batch_solve_async(altro_handle* h) {
+  WIDE_FWD(h, enqueue(0, 0, 0));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   return enqueue_solve(h, 0, 0);
 }
 
 int32_t altro_batch_synchronize(altro_handle* h) {
+  WIDE_FWD(h, synchronize());
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -855,11 +910,13 @@ static int get_traj(altro_handle* h, double* X, double* U) {
 }
 
 int32_t altro_batch_get_states(altro_handle* h, double* X) {
+  WIDE_FWD(h, get_planes(X, nullptr));
   if (!h || !X) return ALTRO_ERR_INVALID_ARG;
   return get_traj(h, X, nullptr);
 }
 
 int32_t altro_batch_get_controls(altro_handle* h, double* U) {
+  WIDE_FWD(h, get_planes(nullptr, U));
   if (!h || !U) return ALTRO_ERR_INVALID_ARG;
   return get_traj(h, nullptr, U);
 }
@@ -897,17 +954,20 @@ static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_ho
 }
 
 int32_t altro_batch_get_duals(altro_handle* h, int32_t con_id, double* lambda) {
+  WIDE_FWD(h, duals(con_id, lambda, false));
   if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
   return duals_xfer(h, con_id, lambda, 1);
 }
 
 int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lambda) {
+  WIDE_FWD(h, duals(con_id, const_cast<double*>(lambda), true));
   if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
   return duals_xfer(h, con_id, const_cast<double*>(lambda), 0);
 }
 
 int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* iterations_outer, int32_t* status,
                               double* cost, double* c_max, double* cost_trace, double* cmax_trace) {
+  WIDE_FWD(h, get_stats(iterations, iterations_outer, status, cost, c_max, cost_trace, cmax_trace));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t B = h->d.batch;
@@ -923,6 +983,7 @@ int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* ite
 }
 
 int32_t altro_batch_get_alpha_trace(altro_handle* h, double* alpha_trace) {
+  WIDE_FWD(h, get_alpha_trace(alpha_trace));
   if (!h || !alpha_trace) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -931,6 +992,7 @@ int32_t altro_batch_get_alpha_trace(altro_handle* h, double* alpha_trace) {
 }
 
 int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
+  WIDE_FWD(h, get_gains(K, d));
   if (!h || (!K && !d)) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -949,6 +1011,7 @@ int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
 }
 
 int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms) {
+  WIDE_FWD(h, last_solve_ms(ms));
   if (!h || !ms) return ALTRO_ERR_INVALID_ARG;
   if (!h->timed) FAIL(h, ALTRO_ERR_STATE, "no solve has been launched");
   HIPCHK(h, hipSetDevice(h->device));
@@ -958,6 +1021,7 @@ int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms) {
 }
 
 int32_t altro_batch_timing_reset(altro_handle* h) {
+  WIDE_FWD(h, timing_reset());
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -973,6 +1037,7 @@ int32_t altro_batch_timing_reset(altro_handle* h) {
 }
 
 int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count) {
+  WIDE_FWD(h, timing_get(ms, capacity, count));
   if (!h || !count) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -984,6 +1049,7 @@ int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int
 }
 
 int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded) {
+  if (h && h->wide) { long long* const src[3] = {h->wide->n_solves, h->wide->n_iters, h->wide->n_ok}; const int rc_ = h->wide->counters(src, solves, iterations, succeeded); if (rc_) h->err = h->wide->err; return rc_; }
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -995,6 +1061,7 @@ int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t
 }
 
 int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts, int64_t* trials) {
+  if (h && h->wide) { long long* const src[3] = {h->wide->n_backward, h->wide->n_rollout, h->wide->n_trials}; const int rc_ = h->wide->counters(src, backward_passes, rollouts, trials); if (rc_) h->err = h->wide->err; return rc_; }
   if (!h) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1006,6 +1073,7 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
 }
 
 int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t capacity, int32_t* count) {
+  if (h && h->wide) { if (count) *count = 0; return ALTRO_OK; }
   if (!h || !count) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1016,6 +1084,7 @@ int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t ca
 }
 
 int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double* Utrack, int32_t Nt) {
+  WIDE_FWD(h, mpc_set_track(Xtrack, Utrack, Nt));
   if (!h || !Xtrack || !Utrack) return ALTRO_ERR_INVALID_ARG;
   if (Nt < h->d.N) FAIL(h, ALTRO_ERR_INVALID_ARG, "track shorter than the horizon");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1042,6 +1111,7 @@ int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double*
 }
 
 int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps) {
+  WIDE_FWD(h, mpc_set_noise(noise, steps));
   if (!h || !noise || steps < 1) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   if (h->noise) HIPCHK(h, hipFree(h->noise));
@@ -1054,6 +1124,7 @@ int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps)
 }
 
 int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups) {
+  WIDE_FWD(h, mpc_set_noise_model(mode, weights, groups));
   if (!h || !weights || mode < 0 || mode > 2) return ALTRO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<double> w(LW, 0.0);
@@ -1071,12 +1142,14 @@ int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* w
 }
 
 int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift) {
+  if (h && h->wide) { h->wide->mpc_shift = shift ? 1 : 0; return ALTRO_OK; }
   if (!h) return ALTRO_ERR_INVALID_ARG;
   h->mpc_shift = shift ? 1 : 0;
   return ALTRO_OK;
 }
 
 int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps) {
+  WIDE_FWD(h, mpc_run(first_step, nsteps));
   if (!h) return ALTRO_ERR_INVALID_ARG;
   if (nsteps < 1 || first_step < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad step range");
   if (h->noise && first_step + nsteps > h->noise_steps) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps outside the uploaded noise");
@@ -1087,6 +1160,7 @@ int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps)
 int32_t altro_mpc_step_async(altro_handle* h, int32_t step) { return altro_mpc_run_async(h, step, 1); }
 
 int32_t altro_batch_get_stream(altro_handle* h, void** stream) {
+  if (h && h->wide && stream) { *stream = (void*)h->wide->stream; return ALTRO_OK; }
   if (!h || !stream) return ALTRO_ERR_INVALID_ARG;
   *stream = (void*)h->stream;
   return ALTRO_OK;

@@ -1,0 +1,756 @@
+// solve_wide.h -- AL-iLQR for problem sizes the 16-lane kernel (solve_dpp16.h) cannot hold:
+// 16 < n + m, n <= 64, m <= 32 (quadruped n = m = 12 with per-knot affine dynamics; the
+// state- and control-dimension sweeps of run_random_linear.jl:128-153; the (12,6) horizon sweep).
+//
+// Mapping: ONE wavefront = ONE MPC instance, sizes are runtime values.  The knot matrices live in
+// LDS, zero-padded to multiples of 16, and the three Riccati contractions
+//     W = S [A B],   [Qxx Qux' ; Qux Quu] = [A B]' W,   S += Qux' K
+// run on the matrix cores as v_mfma_f64_16x16x4_f64 tiles (north_star: "MFMA only when n, m fill a
+// tile").  Every product is phrased as C = AT' B with AT and B row-major in LDS, so both operand
+// fetches are lane-consecutive ds_read_b64 (A-operand lane l holds AT[k0 + l/16][i0 + l%16]); the
+// symmetric S serves as its own transpose.  Leading dimensions are odd, so the column accesses
+// of the vector phases (a lane walking down a column) do not collide in the LDS banks.
+// Vector work (cost expansion, Quu = L D L', the triangular solves for K and d, rollouts) is
+// lane-per-element with wave reductions; rollouts read the dynamics from global memory in the
+// ABI's own column-major layout (lane i = row i: coalesced) and trajectories, duals and gains
+// use the ABI layouts directly, so this path needs no pack kernels.
+//
+// Semantics follow oracle/altro_oracle.c statement by statement; the line
+// search uses true closed-loop rollouts for every alpha, as the reference does.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/altro_batch.h"
+
+namespace altro_wide {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxN = 64, kMaxM = 32, kMaxP = 64;
+
+struct Params {
+  int B, n, m, N, Nt, np, mp, Pn, Pp;
+  int ltv, dyn_per_instance;
+  const double *A, *Bm, *f;            // column-major blocks [inst or 1][N-1 or 1][n*n | n*m | n]
+  const double *wd, *wf, *zmin, *zmax;  // [n+m] stage weights (x dt), [n] terminal, [n+m] box
+  int box_k0, box_k1;
+  const double* AconT;  // [N][n+m][Pn]: row r of knot k's table is column r
+  const double* bcon;   // [N][Pn]
+  const int* ctype;     // [N][Pn]: 0 none, 1 equality, 2 inequality
+  const int *rowk0, *rowk1;  // [Pn] knot range of the constraint block that owns row r
+  double* x0;           // [B][n]
+  const double *Xref, *Uref;  // [B][Nt][n], [B][Nt-1][m]
+  double *X, *U;        // [B][2][N][n], [B][2][N-1][m]
+  int* cur;             // [B]
+  double *Lb, *Lc, *mu; // [B][N][2][n+m], [B][N][Pn], [B]
+  double *Kg, *dg;      // [B][N-1][n][m] (m x n column-major), [B][N-1][m]
+  int *iters, *iters_outer, *status;
+  double *cost, *cmax, *Jtrace, *ctrace, *atrace;
+  long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok;
+  const double *noise, *noise_w;
+  const int* noise_grp;
+  int noise_mode, mpc_shift;
+  int kref;
+  altro_opts o;
+};
+
+__host__ __device__ inline int pad16(int v) { return (v + 15) & ~15; }
+__host__ __device__ inline int pad4(int v) { return (v + 3) & ~3; }
+
+// LDS carve-up (offsets in doubles)
+struct Lds {
+  int G, S, W, Hux, Kl, Huu, Ac, DA, vec, total;
+  int ldg, lds, ldh, ldu;
+};
+__host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
+  Lds L;
+  const int np = pad16(n), mp = pad16(m), nzp = np + mp, Pp = pad4(Pn);
+  L.ldg = nzp + 1;
+  L.lds = np + 1;
+  L.ldh = np + 17;
+  L.ldu = mp + 1;
+  int o = 0;
+  L.G = o; o += np * L.ldg;
+  L.S = o; o += np * L.lds;
+  L.W = o; o += np * L.ldg;
+  L.Hux = o; o += mp * L.ldh;
+  L.Kl = o; o += mp * L.ldh;
+  L.Huu = o; o += mp * L.ldu;
+  L.Ac = o; o += Pp * L.ldg;
+  L.DA = o; o += Pp * L.ldg;
+  L.vec = o; o += 6 * nzp + 2 * np + 2 * (Pp + 4);
+  L.total = o;
+  return L;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ bool wave_any(bool f) { return __ballot(f) != 0ull; }
+
+// C[M x Nn] (ldc) = (ACC ? C : 0) + scale * sum_k AT[k][i] B[k][j];  M, Nn multiples of 16, K of 4
+template <bool ACC>
+__device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int M,
+                                        int Nn, int K, double scale = 1.0) {
+  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
+  for (int i0 = 0; i0 < M; i0 += 16)
+    for (int j0 = 0; j0 < Nn; j0 += 16) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const double a = AT[(k0 + q) * lda + i0 + r16];
+        const double b = Bq[(k0 + q) * ldb + j0 + r16];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* c = C + (i0 + q + 4 * r) * ldc + j0 + r16;
+        const double v = scale * acc[r];
+        *c = ACC ? (*c + v) : v;
+      }
+    }
+}
+
+struct Solver {
+  const Params& P;
+  const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
+  const Lds ly;
+  double *G, *S, *W, *Hux, *Kl, *Huu, *Ac, *DA;
+  double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr;
+  double *Xi, *Ui, *Lbi, *Lci, *Kgi, *dgi, *x0i;
+  const double *Xri, *Uri;
+  int cur, kref;
+  double mu, rho, drho;
+  int dj_zero, status, iters, iters_outer;
+  long long nbw, nro, ntr;
+
+  __device__ Solver(const Params& p, double* lds)
+      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(p.np), mp(p.mp), nz(p.n + p.m),
+        nzp(p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(p.n, p.m, p.Pn)) {
+    G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
+    Ac = lds + ly.Ac; DA = lds + ly.DA;
+    double* v = lds + ly.vec;
+    zb = v; v += nzp; qz = v; v += nzp; hz = v; v += nzp; qv = v; v += nzp; v += 2 * nzp;
+    dxv = v; v += np; sv = v; v += np; gr = v; v += Pp + 4; Dr = v;
+    const size_t b = inst;
+    Xi = P.X + b * 2 * N * n; Ui = P.U + b * 2 * (N - 1) * m;
+    Lbi = P.Lb + b * N * 2 * nz; Lci = P.Lc + b * N * (Pn > 0 ? Pn : 1);
+    Kgi = P.Kg + b * (N - 1) * n * m; dgi = P.dg + b * (N - 1) * m;
+    x0i = P.x0 + b * n;
+    Xri = P.Xref + b * P.Nt * n; Uri = P.Uref + b * (P.Nt - 1) * m;
+    for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ size_t dynblk(int k) const {
+    return (size_t)(P.dyn_per_instance ? inst : 0) * (P.ltv ? (N - 1) : 1) + (P.ltv ? k : 0);
+  }
+  __device__ __forceinline__ const double* Ak(int k) const { return P.A + dynblk(k) * n * n; }
+  __device__ __forceinline__ const double* Bk(int k) const { return P.Bm + dynblk(k) * n * m; }
+  __device__ __forceinline__ const double* fk(int k) const { return P.f + dynblk(k) * n; }
+  __device__ __forceinline__ bool box_at(int k) const { return k >= P.box_k0 && k <= P.box_k1; }
+  __device__ __forceinline__ double* Xp(int pl) const { return Xi + (size_t)pl * N * n; }
+  __device__ __forceinline__ double* Up(int pl) const { return Ui + (size_t)pl * (N - 1) * m; }
+
+  // AL cost of one box-bounded element
+  static __device__ __forceinline__ double lane_cost(double w, double z, double zr, double zmx, double zmn, double lhi,
+                                                     double llo, double mu, bool box_on, double& viol) {
+    const double e = z - zr;
+    double J = 0.5 * w * e * e;
+    if (box_on && zmx < 1e300) {
+      const double c = z - zmx;
+      const bool a = (c >= 0.0) || (lhi > 0.0);
+      J += lhi * c + (a ? 0.5 * mu * c * c : 0.0);
+      viol = fmax(viol, c);
+    }
+    if (box_on && zmn > -1e300) {
+      const double c = zmn - z;
+      const bool a = (c >= 0.0) || (llo > 0.0);
+      J += llo * c + (a ? 0.5 * mu * c * c : 0.0);
+      viol = fmax(viol, c);
+    }
+    return J;
+  }
+
+  // value of generic row r at knot k from zb (padded layout: x at [0,n), u at [np, np+m))
+  __device__ __forceinline__ double row_value(int k, int r, bool term) const {
+    double v = P.bcon[(size_t)k * Pn + r];
+    const double* At = P.AconT + (size_t)k * nz * Pn + r;
+    for (int c = 0; c < n; ++c) v += At[(size_t)c * Pn] * zb[c];
+    if (!term)
+      for (int a = 0; a < m; ++a) v += At[(size_t)(n + a) * Pn] * zb[np + a];
+    return v;
+  }
+
+  // cost!(obj, z_k) + max_violation of knot k; zb holds [x; u] of the knot (synchronised)
+  __device__ void eval_knot(int k, bool term, double xv, double uv, double& J, double& viol) const {
+    const bool bx = box_at(k);
+    if (T < n) {
+      const double lhi = bx ? Lbi[((size_t)k * 2 + 0) * nz + T] : 0.0, llo = bx ? Lbi[((size_t)k * 2 + 1) * nz + T] : 0.0;
+      J += lane_cost(term ? P.wf[T] : P.wd[T], xv, Xri[(size_t)(kref + k) * n + T], P.zmax[T], P.zmin[T], lhi, llo, mu, bx, viol);
+    }
+    if (!term && T < m) {
+      const int j = n + T;
+      const double lhi = bx ? Lbi[((size_t)k * 2 + 0) * nz + j] : 0.0, llo = bx ? Lbi[((size_t)k * 2 + 1) * nz + j] : 0.0;
+      J += lane_cost(P.wd[j], uv, Uri[(size_t)(kref + k) * m + T], P.zmax[j], P.zmin[j], lhi, llo, mu, bx, viol);
+    }
+    if (T < Pn) {
+      const int ct = P.ctype[(size_t)k * Pn + T];
+      if (ct != 0) {
+        const double v = row_value(k, T, term), lam = Lci[(size_t)k * Pn + T];
+        const bool eq = ct == 1;
+        const bool act = eq || (v >= 0.0) || (lam > 0.0);
+        J += lam * v + (act ? 0.5 * mu * v * v : 0.0);
+        viol = fmax(viol, eq ? fabs(v) : v);
+      }
+    }
+  }
+
+  struct RollOut {
+    double J, cmax;
+    bool limit;
+  };
+
+  // rollout!(solver[, alpha]): open loop in place on plane cur, or closed loop from plane cur into
+  // plane cur^1 (oracle rollout_open / rollout_alpha), fused with cost! and max_violation
+  __device__ RollOut rollout(bool open, double alpha) {
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    double* Xd = open ? Xp(cur) : Xp(cur ^ 1);
+    double* Ud = open ? Up(cur) : Up(cur ^ 1);
+    double J = 0.0, viol = 0.0;
+    bool lim = false;
+    double xb = T < n ? x0i[T] : 0.0;
+    for (int k = 0; k < N - 1; ++k) {
+      if (T < n) {
+        zb[T] = xb;
+        if (!open) dxv[T] = xb - Xs[(size_t)k * n + T];
+        Xd[(size_t)k * n + T] = xb;
+      }
+      __syncthreads();
+      double uv = 0.0;
+      if (T < m) {
+        double acc = Us[(size_t)k * m + T];
+        if (!open) {
+          acc += alpha * dgi[(size_t)k * m + T];
+          const double* Kk = Kgi + (size_t)k * n * m + T;
+          for (int j = 0; j < n; ++j) acc += Kk[(size_t)j * m] * dxv[j];
+          Ud[(size_t)k * m + T] = acc;
+        }
+        uv = acc;
+        zb[np + T] = acc;
+      }
+      __syncthreads();
+      eval_knot(k, false, xb, uv, J, viol);
+      lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
+      double xn = 0.0;
+      if (T < n) {
+        const double *A_ = Ak(k) + T, *B_ = Bk(k) + T;
+        double acc = fk(k)[T];
+        for (int j = 0; j < n; ++j) acc += A_[(size_t)j * n] * zb[j];
+        for (int a = 0; a < m; ++a) acc += B_[(size_t)a * n] * zb[np + a];
+        xn = acc;
+      }
+      __syncthreads();
+      xb = xn;
+    }
+    if (T < n) {
+      zb[T] = xb;
+      Xd[(size_t)(N - 1) * n + T] = xb;
+    }
+    __syncthreads();
+    eval_knot(N - 1, true, xb, 0.0, J, viol);
+    lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value));
+    __syncthreads();
+    RollOut r;
+    r.J = wave_sum(J);
+    r.cmax = wave_max(viol);
+    r.limit = wave_any(lim);
+    return r;
+  }
+
+  __device__ void load_dyn(int k) {
+    const double *A_ = Ak(k), *B_ = Bk(k);
+    for (int e = T; e < n * n; e += 64) {
+      const int j = e / n, i = e - j * n;
+      G[i * ly.ldg + j] = A_[e];
+    }
+    for (int e = T; e < n * m; e += 64) {
+      const int a = e / n, i = e - a * n;
+      G[i * ly.ldg + np + a] = B_[e];
+    }
+  }
+
+  static __device__ __forceinline__ void box_expand(double mu, double z, double zmx, double zmn, double lhi, double llo,
+                                                    double& q, double& h) {
+    if (zmx < 1e300) {
+      const double c = z - zmx;
+      const bool a = (c >= 0.0) || (lhi > 0.0);
+      q += lhi + (a ? mu * c : 0.0);
+      h += a ? mu : 0.0;
+    }
+    if (zmn > -1e300) {
+      const double c = zmn - z;
+      const bool a = (c >= 0.0) || (llo > 0.0);
+      q -= llo + (a ? mu * c : 0.0);
+      h += a ? mu : 0.0;
+    }
+  }
+
+  // cost_expansion! at knot k of plane cur: gradient qz, Hessian diagonal hz (padded z layout), and
+  // for the generic rows the tables Ac, DA = diag(I_mu) Ac with A'g already added to qz
+  __device__ void expansion(int k, bool term) {
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    const bool bx = box_at(k);
+    if (T < n) {
+      const double x = Xs[(size_t)k * n + T];
+      zb[T] = x;
+      const double w = term ? P.wf[T] : P.wd[T];
+      double q = w * (x - Xri[(size_t)(kref + k) * n + T]), h = w;
+      if (bx) box_expand(mu, x, P.zmax[T], P.zmin[T], Lbi[((size_t)k * 2) * nz + T], Lbi[((size_t)k * 2 + 1) * nz + T], q, h);
+      qz[T] = q;
+      hz[T] = h;
+    }
+    if (T < m) {
+      double q = 0.0, h = 0.0, u = 0.0;
+      if (!term) {
+        const int j = n + T;
+        u = Us[(size_t)k * m + T];
+        const double w = P.wd[j];
+        q = w * (u - Uri[(size_t)(kref + k) * m + T]);
+        h = w;
+        if (bx) box_expand(mu, u, P.zmax[j], P.zmin[j], Lbi[((size_t)k * 2) * nz + j], Lbi[((size_t)k * 2 + 1) * nz + j], q, h);
+      }
+      zb[np + T] = u;
+      qz[np + T] = q;
+      hz[np + T] = h;
+    }
+    __syncthreads();
+    if (Pn > 0) {
+      if (T < Pp) {
+        double g = 0.0, D = 0.0;
+        if (T < Pn) {
+          const int ct = P.ctype[(size_t)k * Pn + T];
+          if (ct != 0) {
+            const double v = row_value(k, T, term), lam = Lci[(size_t)k * Pn + T];
+            const bool act = (ct == 1) || (v >= 0.0) || (lam > 0.0);
+            g = lam + (act ? mu * v : 0.0);
+            D = act ? mu : 0.0;
+          }
+        }
+        gr[T] = g;
+        Dr[T] = D;
+      }
+      __syncthreads();
+      const double* At = P.AconT + (size_t)k * nz * Pn;
+      for (int e = T; e < nz * Pn; e += 64) {
+        const int j = e / Pn, r = e - j * Pn;
+        const double v = (term && j >= n) ? 0.0 : At[e];
+        const int c = j < n ? j : np + (j - n);
+        Ac[r * ly.ldg + c] = v;
+        DA[r * ly.ldg + c] = Dr[r] * v;
+      }
+      __syncthreads();
+      for (int c = T; c < nzp; c += 64) {
+        double acc = 0.0;
+        for (int r = 0; r < Pn; ++r) acc += Ac[r * ly.ldg + c] * gr[r];
+        qz[c] += acc;
+      }
+      __syncthreads();
+    }
+  }
+
+  // backwardpass! (oracle backward_pass).  Returns true if a pivot of Quu + rho I was not positive.
+  __device__ bool backward(double& dV1, double& dV2) {
+    const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
+    for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
+    __syncthreads();
+    expansion(N - 1, true);
+    if (T < n) {
+      S[T * lds + T] = hz[T];
+      sv[T] = qz[T];
+    }
+    __syncthreads();
+    if (Pn > 0) gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
+    dV1 = 0.0;
+    dV2 = 0.0;
+    if (!P.ltv) load_dyn(0);
+    __syncthreads();
+    for (int k = N - 2; k >= 0; --k) {
+      if (P.ltv) load_dyn(k);
+      expansion(k, false);  // ends with a barrier
+      // Q_z = l_z + [A B]' s
+      for (int c = T; c < nzp; c += 64) {
+        double acc = qz[c];
+        for (int i = 0; i < n; ++i) acc += G[i * ldg + c] * sv[i];
+        qv[c] = acc;
+      }
+      gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
+      __syncthreads();
+      gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
+      gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
+      gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
+      __syncthreads();
+      if (T < n) S[T * lds + T] += hz[T];
+      if (T < m) {
+        Huu[T * ldu + T] += hz[np + T];
+        Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
+      }
+      __syncthreads();
+      if (Pn > 0) {
+        gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
+        gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
+        gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
+        __syncthreads();
+      }
+      for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];
+      if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
+      __syncthreads();
+      // Quu_reg = L D L' in place (unit L below the diagonal, D on it)
+      for (int j = 0; j < m; ++j) {
+        const double dj = Huu[j * ldu + j];
+        if (!(dj > 0.0)) return true;  // wave-uniform
+        if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
+        __syncthreads();
+        if (T > j && T < m) {
+          const double li = Huu[T * ldu + j];
+          for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
+        }
+        __syncthreads();
+      }
+      // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
+      for (int c = T; c <= np; c += 64) {
+        if (c < n || c == np) {
+          for (int i = 0; i < m; ++i) {
+            double v = Kl[i * ldh + c];
+            for (int kk = 0; kk < i; ++kk) v -= Huu[i * ldu + kk] * Kl[kk * ldh + c];
+            Kl[i * ldh + c] = v;
+          }
+          for (int i = 0; i < m; ++i) Kl[i * ldh + c] /= Huu[i * ldu + i];
+          for (int i = m - 1; i >= 0; --i) {
+            double v = Kl[i * ldh + c];
+            for (int kk = i + 1; kk < m; ++kk) v -= Huu[kk * ldu + i] * Kl[kk * ldh + c];
+            Kl[i * ldh + c] = v;
+          }
+          for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
+        }
+      }
+      __syncthreads();
+      // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
+      {
+        double t1 = 0.0, dd = 0.0;
+        if (T < m) {
+          const double d = Kl[T * ldh + np];
+          t1 = d * Hux[T * ldh + np];
+          dd = d * d;
+        }
+        t1 = wave_sum(t1);
+        dd = wave_sum(dd);
+        dV1 += t1;
+        dV2 += -0.5 * t1 - 0.5 * rho * dd;
+      }
+      // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
+      gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
+      if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
+      if (T < n) {
+        double acc = qv[T];
+        for (int a = 0; a < m; ++a) acc += (Hux[a * ldh + T] - rho * Kl[a * ldh + T]) * Kl[a * ldh + np];
+        sv[T] = acc;
+      }
+      __syncthreads();
+      for (int e = T; e < n * n; e += 64) {  // S <- (S + S')/2
+        const int i = e / n, j = e - i * n;
+        if (i > j) {
+          const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
+          S[i * lds + j] = v;
+          S[j * lds + i] = v;
+        }
+      }
+      double* Kk = Kgi + (size_t)k * n * m;
+      for (int e = T; e < n * m; e += 64) {
+        const int j = e / m, a = e - j * m;
+        Kk[e] = Kl[a * ldh + j];
+      }
+      if (T < m) dgi[(size_t)k * m + T] = Kl[T * ldh + np];
+      __syncthreads();
+    }
+    return false;
+  }
+
+  __device__ void reg_update(bool increase) {
+    const altro_opts& o = P.o;
+    if (increase) {
+      drho = fmax(drho * o.bp_reg_increase_factor, o.bp_reg_increase_factor);
+      rho = fmax(rho * drho, o.bp_reg_min);
+    } else {
+      drho = fmin(drho / o.bp_reg_increase_factor, 1.0 / o.bp_reg_increase_factor);
+      rho = rho * drho * ((rho * drho > o.bp_reg_min) ? 1.0 : 0.0);
+    }
+  }
+
+  // gradient_todorov! on plane cur
+  __device__ double todorov() const {
+    const double* Us = Up(cur);
+    double acc = 0.0;
+    for (int k = 0; k < N - 1; ++k) {
+      double v = 0.0;
+      if (T < m) v = fabs(dgi[(size_t)k * m + T]) / (fabs(Us[(size_t)k * m + T]) + 1.0);
+      acc += wave_max(v);
+    }
+    return acc / (double)(N - 1);
+  }
+
+  // solve!(::iLQRSolver) (oracle ilqr_solve); returns the final cost, cmax by reference
+  __device__ double ilqr(double cost_tol, double grad_tol, double& cmax) {
+    const altro_opts& o = P.o;
+    rho = o.bp_reg_initial;
+    drho = 0.0;
+    dj_zero = 0;
+    RollOut r0 = rollout(true, 0.0);
+    nro++;
+    if (r0.limit) {
+      status = ALTRO_STATE_LIMIT;
+      cmax = __builtin_inf();
+      return __builtin_inf();
+    }
+    double J_prev = r0.J, J = r0.J;
+    cmax = r0.cmax;
+    for (int it = 0; it < o.iterations_inner; ++it) {
+      double dV1, dV2;
+      bool gave_up = false;
+      while (true) {  // regularisation restarts
+        const bool fail = backward(dV1, dV2);
+        nbw++;
+        __syncthreads();
+        if (!fail) break;
+        if (rho >= o.bp_reg_max) { gave_up = true; break; }
+        reg_update(true);
+      }
+      if (gave_up) { status = ALTRO_NO_PROGRESS; break; }
+      reg_update(false);
+      // forwardpass!
+      double alpha = 1.0, z = -1.0, cm = 0.0;
+      J = __builtin_inf();
+      int ls = 0;
+      bool accepted = true;
+      while ((z <= o.line_search_lower_bound || z > o.line_search_upper_bound) && J >= J_prev) {
+        if (ls > o.iterations_linesearch) {
+          J = J_prev;
+          cm = cmax;
+          alpha = 0.0;
+          accepted = false;
+          reg_update(true);
+          rho += o.bp_reg_fp;
+          break;
+        }
+        const RollOut r = rollout(false, alpha);
+        if (ls == 0) nro++; else ntr++;
+        if (r.limit) { ls++; alpha *= 0.5; continue; }
+        J = r.J;
+        cm = r.cmax;
+        const double expected = -alpha * (dV1 + alpha * dV2);
+        z = expected > 0.0 ? (J_prev - J) / expected : -1.0;
+        ls++;
+        alpha *= 0.5;
+      }
+      if (accepted) alpha *= 2.0;
+      if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
+      if (accepted) cur ^= 1;  // copy_trajectories!
+      cmax = cm;
+      const double dJ = fabs(J - J_prev);
+      J_prev = J;
+      if (iters < ALTRO_TRACE_LEN && T == 0) {
+        P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + iters] = J;
+        P.ctrace[(size_t)inst * ALTRO_TRACE_LEN + iters] = cm;
+        P.atrace[(size_t)inst * ALTRO_TRACE_LEN + iters] = alpha;
+      }
+      iters++;
+      dj_zero = (dJ == 0.0) ? dj_zero + 1 : 0;
+      if (dJ < cost_tol && todorov() < grad_tol) break;
+      if (iters >= o.iterations) { status = ALTRO_MAX_ITERATIONS; break; }
+      if (dj_zero > o.dJ_counter_limit) { status = ALTRO_NO_PROGRESS; break; }
+    }
+    return J;
+  }
+
+  // dual_update! on plane cur (the penalty is scaled by the caller)
+  __device__ void dual_update() {
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    const double dmax = P.o.dual_max;
+    for (int k = 0; k < N; ++k) {
+      const bool term = k == N - 1;
+      double xv = 0.0, uv = 0.0;
+      if (T < n) { xv = Xs[(size_t)k * n + T]; zb[T] = xv; }
+      if (T < m) { uv = term ? 0.0 : Us[(size_t)k * m + T]; zb[np + T] = uv; }
+      __syncthreads();
+      if (box_at(k)) {
+        for (int pass = 0; pass < 2; ++pass) {
+          const bool on = pass == 0 ? (T < n) : (T < m && !term);
+          if (!on) continue;
+          const int j = pass == 0 ? T : n + T;
+          const double z = pass == 0 ? xv : uv;
+          if (P.zmax[j] < 1e300) {
+            double* l = Lbi + ((size_t)k * 2) * nz + j;
+            *l = fmin(fmax(*l + mu * (z - P.zmax[j]), 0.0), dmax);
+          }
+          if (P.zmin[j] > -1e300) {
+            double* l = Lbi + ((size_t)k * 2 + 1) * nz + j;
+            *l = fmin(fmax(*l + mu * (P.zmin[j] - z), 0.0), dmax);
+          }
+        }
+      }
+      if (T < Pn) {
+        const int ct = P.ctype[(size_t)k * Pn + T];
+        if (ct != 0) {
+          double* l = Lci + (size_t)k * Pn + T;
+          const double v = *l + mu * row_value(k, T, term);
+          *l = fmin(fmax(v, ct == 1 ? -dmax : 0.0), dmax);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // RD.shift_fill!(Z) and Altro.shift_fill!(conSet) on plane cur (oracle orc_shift_fill)
+  __device__ void shift(bool primal, bool dual) {
+    if (primal) {
+      double* Xs = Xp(cur);
+      double* Us = Up(cur);
+      if (T < n) for (int k = 0; k + 1 < N; ++k) Xs[(size_t)k * n + T] = Xs[(size_t)(k + 1) * n + T];
+      if (T < m) for (int k = 0; k + 2 < N; ++k) Us[(size_t)k * m + T] = Us[(size_t)(k + 1) * m + T];
+    }
+    if (dual) {
+      for (int e = T; e < 2 * nz; e += 64)
+        for (int k = P.box_k0; k < P.box_k1; ++k) Lbi[(size_t)k * 2 * nz + e] = Lbi[(size_t)(k + 1) * 2 * nz + e];
+      if (T < Pn)
+        for (int k = P.rowk0[T]; k < P.rowk1[T]; ++k) Lci[(size_t)k * Pn + T] = Lci[(size_t)(k + 1) * Pn + T];
+    }
+    __syncthreads();
+  }
+
+  // plant step of the device MPC loop: x0 <- A x_1 + B u_1 + f + noise (time-invariant dynamics only)
+  __device__ void plant_step(int step) {
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    if (T < n) zb[T] = Xs[T];
+    if (T < m) zb[np + T] = Us[T];
+    __syncthreads();
+    double xn = 0.0;
+    if (T < n) {
+      const double *A_ = Ak(0) + T, *B_ = Bk(0) + T;
+      double acc = fk(0)[T];
+      for (int j = 0; j < n; ++j) acc += A_[(size_t)j * n] * zb[j];
+      for (int a = 0; a < m; ++a) acc += B_[(size_t)a * n] * zb[np + a];
+      xn = acc;
+    }
+    double nrm = 1.0;
+    if (P.noise_mode == 0) {
+      nrm = wave_max(T < n ? fabs(xn) : 0.0);
+    } else if (P.noise_mode == 1) {
+      const int g = T < n ? P.noise_grp[T] : -1;
+      const double n0 = sqrt(wave_sum(g == 0 ? xn * xn : 0.0)), n1 = sqrt(wave_sum(g == 1 ? xn * xn : 0.0));
+      nrm = g == 0 ? n0 : n1;
+    }
+    if (T < n) {
+      const double nzv = P.noise ? P.noise[((size_t)step * P.B + inst) * n + T] : 0.0;
+      x0i[T] = xn + nzv * nrm * P.noise_w[T];
+    }
+    __syncthreads();
+  }
+
+  // solve!(::ALTROSolver) (oracle orc_solve)
+  __device__ void solve_one() {
+    const altro_opts& o = P.o;
+    const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
+    const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
+    const bool has_con = (P.box_k1 >= P.box_k0) || Pn > 0;
+    if (o.reset_duals) {
+      for (int e = T; e < N * 2 * nz; e += 64) Lbi[e] = 0.0;
+      for (int e = T; e < N * Pn; e += 64) Lci[e] = 0.0;
+    }
+    if (o.reset_penalties) mu = mu0;
+    status = ALTRO_UNSOLVED;
+    iters = 0;
+    iters_outer = 0;
+    __syncthreads();
+    double J = 0.0, cmax = 0.0;
+    if (!has_con) {
+      J = ilqr(o.cost_tolerance, o.gradient_tolerance, cmax);
+      cmax = 0.0;
+      if (status == ALTRO_UNSOLVED) status = ALTRO_SOLVE_SUCCEEDED;
+    } else {
+      for (int jo = 0; jo < o.iterations_outer; ++jo) {
+        const bool last = jo == o.iterations_outer - 1;
+        J = ilqr(last ? o.cost_tolerance : o.cost_tolerance_intermediate,
+                 last ? o.gradient_tolerance : o.gradient_tolerance_intermediate, cmax);
+        iters_outer++;
+        if (status > ALTRO_SOLVE_SUCCEEDED) break;
+        if (cmax < o.constraint_tolerance || mu >= o.penalty_max) break;
+        if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
+        dual_update();
+        mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
+      }
+      if (status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance) status = ALTRO_SOLVE_SUCCEEDED;
+    }
+    if (T == 0) {
+      P.cost[inst] = J;
+      P.cmax[inst] = cmax;
+      P.status[inst] = status;
+      P.iters[inst] = iters;
+      P.iters_outer[inst] = iters_outer;
+    }
+  }
+
+  __device__ void run(int mpc, int first_step, int nsteps) {
+    cur = P.cur[inst];
+    mu = P.mu[inst];
+    kref = P.kref;
+    nbw = nro = ntr = 0;
+    long long nsolve = 0, nit = 0, nok = 0;
+    const int steps = mpc ? nsteps : 1;
+    for (int s = 0; s < steps; ++s) {
+      if (mpc) {
+        plant_step(first_step + s);
+        kref = first_step + s + 1;  // update_trajectory!(obj, Z_track, k_mpc)
+        if (P.mpc_shift) shift(true, true);
+      }
+      solve_one();
+      nsolve++;
+      nit += iters;
+      nok += status == ALTRO_SOLVE_SUCCEEDED ? 1 : 0;
+    }
+    if (T == 0) {
+      P.cur[inst] = cur;
+      P.mu[inst] = mu;
+      P.n_backward[inst] += nbw;
+      P.n_rollout[inst] += nro;
+      P.n_trials[inst] += ntr;
+      P.n_solves[inst] += nsolve;
+      P.n_iters[inst] += nit;
+      P.n_ok[inst] += nok;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(64) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
+  extern __shared__ double lds[];
+  Solver s(P, lds);
+  s.run(mpc, first_step, nsteps);
+}
+
+// the separate shift_fill call of the fine-grained ABI
+__global__ void __launch_bounds__(64) wide_shift_kernel(Params P, int primal, int dual) {
+  extern __shared__ double lds[];
+  Solver s(P, lds);
+  s.cur = P.cur[s.inst];
+  s.shift(primal != 0, dual != 0);
+}
+
+}  // namespace altro_wide

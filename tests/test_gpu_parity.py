@@ -66,6 +66,36 @@ def test_mpc_loop_matches_oracle(oracle, n, m, N):
             assert np.array_equal(X[b, 0], x0g[b])  # :err_x0 of the reference is identically 0
 
 
+@pytest.mark.parametrize("n,m,N", [(12, 6, 31), (2, 2, 21), (15, 2, 21), (35, 2, 21), (55, 2, 21), (30, 10, 21), (30, 25, 21)])
+def test_mpc_loop_wide_kernel_sizes_match_oracle(oracle, n, m, N):
+    """Sizes outside the 16-lane kernel set run on the one-wave-per-instance MFMA kernel
+    (solve_wide.h): the horizon sweep's (12, 6), and points of the state- and control-dimension
+    sweeps (run_random_linear.jl:110-153: n in {2..55} with m = 2, m in {2..25} with n = 30)."""
+    B, S = 5, 4
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=21)
+    mp = altro.mpc.BatchMPC(pb)
+    assert altro.wave_cycles(mp.solver).size == 0        # the 16-lane kernel's diagnostic is absent: wide path
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    sos = [o.solve() for o in orcs]
+    st = altro.stats(mp.solver)
+    X, U = altro.states(mp.solver), altro.controls(mp.solver)
+    Kg, dg = altro.gains(mp.solver)
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], sos[b])
+        Ko, do = orcs[b].gains()
+        assert rel_err(Kg[b], Ko) <= RTOL and rel_err(dg[b], do) <= RTOL
+    for i in range(S):
+        mp.step(i)
+        st = altro.stats(mp.solver)
+        X, U = altro.states(mp.solver), altro.controls(mp.solver)
+        x0g = mp.x0()
+        for b in range(B):
+            x0 = mpc_update(orcs[b], pb, b, i)
+            assert np.abs(x0 - x0g[b]).max() <= 1e-12 * max(1.0, np.abs(x0).max())
+            check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+
+
 def test_cold_solve_far_from_reference_matches_oracle(oracle):
     """Cold solves from a perturbed initial state: many active bounds, several AL outer
     iterations, line-search activity."""
@@ -520,9 +550,17 @@ def test_update_constraint_data_is_seen_by_the_next_solve(oracle):
 
 
 def test_error_paths():
-    pb = altro.problems.gen_random_linear_batch(2, n=5, m=2, N=9, steps=1)
+    # n > 64 is outside both kernels
+    pb = altro.problems.gen_random_linear_batch(2, n=70, m=2, N=9, steps=1)
     with pytest.raises(altro.AltroError) as e:
         altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
+    assert e.value.code == altro._lib.ERR_UNSUPPORTED
+    # second-order cones are only built into the 16-lane kernels
+    pb = altro.problems.gen_random_linear_batch(2, n=12, m=6, N=9, steps=1)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.constraints.add_constraint(altro.NormConstraint(np.ones((3, 18)), np.zeros(3)), (1, 8))
+    with pytest.raises(altro.AltroError) as e:
+        altro.ALTROSolver(prob)
     assert e.value.code == altro._lib.ERR_UNSUPPORTED
     # a second-order cone of dimension 5 does not fit a quad
     pb = altro.problems.gen_random_linear_batch(2, n=6, m=3, N=9, steps=1)
