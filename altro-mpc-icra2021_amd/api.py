@@ -63,11 +63,14 @@ def SolverOptions(**kw):
 
 @dataclass
 class LinearModel:
-    """x+ = A x + B u (+ d).  A: (n,n) shared or (B,n,n) per instance."""
+    """RD.LinearModel: x+ = A x + B u (+ d).  A: (n,n) shared or (B,n,n) per instance; with
+    per_knot=True (a model built with `times`, ALTROParams.jl:61) one block per knot:
+    (N-1,n,n) or (B,N-1,n,n), d likewise."""
     A: np.ndarray
     B: np.ndarray
     d: Optional[np.ndarray] = None
     dt: float = 0.1
+    per_knot: bool = False
 
 
 @dataclass
@@ -169,13 +172,7 @@ class ALTROSolver:
         self.h = h
         self.con_ids = []
         mdl = prob.model
-        A = np.asarray(mdl.A, dtype=np.float64)
-        Bm = np.asarray(mdl.B, dtype=np.float64)
-        per_instance = A.ndim == 3
-        Ac = _c(np.swapaxes(A, -1, -2))
-        Bc = _c(np.swapaxes(Bm, -1, -2))
-        dc = _c(mdl.d) if mdl.d is not None else None
-        self._chk(L.altro_batch_set_dynamics(h, _p(Ac), _p(Bc), _p(dc), 0, int(per_instance)))
+        set_dynamics(self, mdl)
         self._chk(L.altro_batch_set_tracking_cost(h, _p(_c(prob.obj.Q)), _p(_c(prob.obj.R)), _p(_c(prob.obj.Qf)), mdl.dt))
         for con, first, last in prob.constraints.items:
             if isinstance(con, BoundConstraint):
@@ -217,6 +214,18 @@ class ALTROSolver:
             self.close()
         except Exception:
             pass
+
+
+def set_dynamics(solver, mdl):
+    """Install (or replace) the dynamics: the quadruped controller rewrites model.A[k], B[k], d[k]
+    before every solve (altro_solver.jl:5-37)."""
+    A = np.asarray(mdl.A, dtype=np.float64)
+    Bm = np.asarray(mdl.B, dtype=np.float64)
+    per_instance = A.ndim == (4 if mdl.per_knot else 3)
+    Ac = _c(np.swapaxes(A, -1, -2))
+    Bc = _c(np.swapaxes(Bm, -1, -2))
+    dc = _c(mdl.d) if mdl.d is not None else None
+    solver._chk(solver._L.altro_batch_set_dynamics(solver.h, _p(Ac), _p(Bc), _p(dc), int(mdl.per_knot), int(per_instance)))
 
 
 def set_options(solver, **kw):

@@ -298,3 +298,134 @@ def gen_grasp_problem(N=61, tf=6.0, x0=(0.0, 3.0, 3.0, 0.0, 0.0, 0.0), mu=0.5, m
     return GraspProblemData(n=n, m=m, N=N, dt=dt, A=A, Bm=Bm, f=f, Q=np.full(n, 1e-3), R=np.full(m, 1.0),
                             Qf=np.full(n, 10.0), xf=xf, x0=np.asarray(x0, dtype=float),
                             U0=np.tile(u0, (N - 1, 1)), constraints=cons, theta=theta, p=p, v=v)
+
+
+# ---------------------------------------------------------------------------------------------
+# quadruped contact-switching MPC (BASELINE config 5): reference benchmarks/quadruped/Woofer/MPCControl
+QUADRUPED_OPTS = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-3, constraint_tolerance=1e-4,
+                      penalty_initial=10.0, penalty_scaling=100.0, reset_duals=0)
+"""SolverOptions of Structs/ALTROParams.jl:86-95"""
+
+
+def _skew(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def _mrp_rotation(p):
+    """rotation matrix of a Modified Rodrigues Parameter vector"""
+    s = float(p @ p)
+    P = _skew(p)
+    return np.eye(3) + (8.0 * P @ P + 4.0 * (1.0 - s) * P) / (1.0 + s) ** 2
+
+
+def _mrp_kinematics(p, w):
+    s = float(p @ p)
+    return 0.25 * ((1.0 - s) * np.eye(3) + 2.0 * _skew(p) + 2.0 * np.outer(p, p)) @ w
+
+
+def quadruped_continuous_dynamics(x, u, feet, contacts, inertia, mass):
+    """Single rigid body with four point feet (NonLinearContinuousDynamics,
+    linearized_dynamics.jl:1-38): x = [position; MRP attitude; velocity; body angular velocity],
+    u = four world-frame foot forces; a swing foot (contact 0) exerts nothing."""
+    p, phi, v, w = x[0:3], x[3:6], x[6:9], x[9:12]
+    R = _mrp_rotation(phi)
+    force = np.array([0.0, 0.0, -9.81])
+    torque = np.zeros(3)
+    for i in range(4):
+        fi = u[3 * i:3 * i + 3]
+        force = force + contacts[i] * fi / mass
+        rb = R.T @ (feet[i] - p)                      # foot in the body frame
+        torque = torque + contacts[i] * _skew(rb) @ (R.T @ fi)
+    wdot = np.linalg.solve(inertia, -_skew(w) @ inertia @ w + torque)
+    return np.concatenate([v, _mrp_kinematics(phi, w), force, wdot])
+
+
+def quadruped_linearize(xr, ur, feet, contacts, inertia, mass, dt, eps=1e-6):
+    """A_k, B_k, d_k of update_dynamics_matrices! (altro_solver.jl:5-37): Jacobians of the
+    continuous dynamics at (x_ref, u_ref) (central differences here, ForwardDiff there), affine
+    remainder d = f(x_ref,u_ref) - A x_ref - B u_ref, forward-Euler discretisation."""
+    f0 = quadruped_continuous_dynamics(xr, ur, feet, contacts, inertia, mass)
+    Ac = np.zeros((12, 12))
+    Bc = np.zeros((12, 12))
+    for j in range(12):
+        e = np.zeros(12)
+        e[j] = eps
+        Ac[:, j] = (quadruped_continuous_dynamics(xr + e, ur, feet, contacts, inertia, mass) -
+                    quadruped_continuous_dynamics(xr - e, ur, feet, contacts, inertia, mass)) / (2 * eps)
+        Bc[:, j] = (quadruped_continuous_dynamics(xr, ur + e, feet, contacts, inertia, mass) -
+                    quadruped_continuous_dynamics(xr, ur - e, feet, contacts, inertia, mass)) / (2 * eps)
+    dc = f0 - Ac @ xr - Bc @ ur
+    return np.eye(12) + Ac * dt, Bc * dt, dc * dt
+
+
+def trot_contacts(t, stance_time=0.2, swing_time=0.2):
+    """trot(): four phases [all feet | diagonal pair A | all feet | diagonal pair B]
+    (Structs/GaitParams.jl:38-49, MPC.yaml:2-5)"""
+    phases = np.array([[1, 1, 1, 1], [1, 0, 0, 1], [1, 1, 1, 1], [0, 1, 1, 0]], dtype=float)
+    times = np.array([stance_time, swing_time, stance_time, swing_time])
+    tt = t % times.sum()
+    k = int(np.searchsorted(np.cumsum(times), tt, side="right"))
+    return phases[min(k, 3)]
+
+
+@dataclass
+class QuadrupedData:
+    n: int
+    m: int
+    N: int
+    dt: float
+    Q: np.ndarray
+    R: np.ndarray
+    x_des: np.ndarray
+    u_hover: np.ndarray
+    feet: np.ndarray          # (4, 3) world-frame foot positions of the nominal stance
+    inertia: np.ndarray
+    mass: float
+    mu: float
+    fz_max: float
+    constraints: list         # ConstraintSpec: 4 friction pyramids (LINEAR ineq) + the f_z box
+
+    def dynamics(self, t0, x_ref=None):
+        """per-knot (A, B, d) for a horizon starting at time t0 (contact schedule of the trot)"""
+        xr = self.x_des if x_ref is None else x_ref
+        A = np.zeros((self.N - 1, 12, 12))
+        Bm = np.zeros((self.N - 1, 12, 12))
+        d = np.zeros((self.N - 1, 12))
+        for k in range(self.N - 1):
+            c = trot_contacts(t0 + k * self.dt)
+            A[k], Bm[k], d[k] = quadruped_linearize(xr, np.zeros(12), self.feet, c, self.inertia, self.mass, self.dt)
+        return A, Bm, d
+
+
+def gen_quadruped_problem(N=15, dt=0.03, vx=0.0):
+    """AltroParams (Structs/ALTROParams.jl:32-108) with MPC.yaml's weights: n = m = 12, LQR about
+    x_des with u_ref = 0, per leg the linearised friction pyramid |f_x|, |f_y| <= mu f_z (4 rows,
+    LinearizedFrictionConstraint.jl:14-25) on knots 1..N-1, 0 <= f_z <= 133 on every control."""
+    n = m = 12
+    q = np.array([1.0, 1.0, 500.0, 5000.0, 5000.0, 1000.0, 500.0, 1000.0, 1000.0, 500.0, 500.0, 100.0])
+    r = np.tile([1.0, 1.0, 0.001], 4)
+    mass = 3.0 + 4 * 1.033 + 8 * 0.070                       # sprung mass (Config.jl:56)
+    inertia = np.diag([0.025, 0.854, 0.897])
+    hx, hy, abd, h = 0.230, 0.109, 0.064, 0.28
+    feet = np.array([[hx, hy + abd, 0.0], [hx, -hy - abd, 0.0], [-hx, hy + abd, 0.0], [-hx, -hy - abd, 0.0]])
+    x_des = np.zeros(12)
+    x_des[2] = h
+    x_des[6] = vx
+    mu, fz_max = 0.5, 133.0
+    cons = []
+    for leg in range(4):
+        A = np.zeros((4, n + m))
+        ix, iy, iz = n + 3 * leg, n + 3 * leg + 1, n + 3 * leg + 2
+        A[0, ix], A[0, iz] = 1.0, -mu
+        A[1, ix], A[1, iz] = -1.0, -mu
+        A[2, iy], A[2, iz] = 1.0, -mu
+        A[3, iy], A[3, iz] = -1.0, -mu
+        cons.append(ConstraintSpec(LINEAR, INEQ, 0, N - 2, A=A, b=np.zeros(4)))
+    zmin = np.full(n + m, -np.inf)
+    zmax = np.full(n + m, np.inf)
+    for leg in range(4):
+        zmin[n + 3 * leg + 2], zmax[n + 3 * leg + 2] = 0.0, fz_max
+    cons.append(ConstraintSpec(BOX, INEQ, 0, N - 1, zmin=zmin, zmax=zmax))
+    u_hover = np.tile([0.0, 0.0, 9.81 * mass / 4.0], 4)
+    return QuadrupedData(n=n, m=m, N=N, dt=dt, Q=q, R=r, x_des=x_des, u_hover=u_hover, feet=feet, inertia=inertia,
+                         mass=mass, mu=mu, fz_max=fz_max, constraints=cons)

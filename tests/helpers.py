@@ -115,7 +115,7 @@ def soc_project(v):
 
 
 def admm_conic_qp(Pm, q, G, h, cones, rho=1.0, sigma=1e-6, iters=20000, tol=1e-9):
-    """min 1/2 x'Px + q'x  s.t.  G x + h in K,  K = product of cones [("zero"|"soc", dim), ...].
+    """min 1/2 x'Px + q'x  s.t.  G x + h in K,  K = product of cones [("zero"|"nonneg"|"soc", dim), ...].
     Operator-splitting (OSQP / COSMO form): an algorithm independent of AL-iLQR, used only to pin
     the oracle's converged conic solutions, as the reference pins ALTRO against COSMO / ECOS
     (simple_rocket.jl:183-203)."""
@@ -130,7 +130,7 @@ def admm_conic_qp(Pm, q, G, h, cones, rho=1.0, sigma=1e-6, iters=20000, tol=1e-9
         i = 0
         for kind, d in cones:
             seg = w[i:i + d] + h[i:i + d]
-            out[i:i + d] = (0.0 if kind == "zero" else soc_project(seg)) - h[i:i + d]
+            out[i:i + d] = (0.0 if kind == "zero" else np.maximum(seg, 0.0) if kind == "nonneg" else soc_project(seg)) - h[i:i + d]
             i += d
         return out
 
@@ -144,3 +144,73 @@ def admm_conic_qp(Pm, q, G, h, cones, rho=1.0, sigma=1e-6, iters=20000, tol=1e-9
         if it > 10 and rp_ < tol and rd_ < tol:
             break
     return x, it
+
+
+# ---------------------------------------------------------------------------------------------
+# quadruped (per-knot affine dynamics, friction pyramids, f_z box): oracle / GPU set-up
+def quadruped_oracle(O, qp, x0, A, Bm, d, opts):
+    s = O.OracleSolver(qp.n, qp.m, qp.N, qp.dt)
+    s.set_dynamics(A, Bm, d)
+    s.set_cost(qp.Q, qp.R, qp.Q)
+    s.set_reference(np.tile(qp.x_des, (qp.N, 1)), np.zeros((qp.N - 1, qp.m)))
+    s.set_initial_state(x0)
+    s.set_controls(np.tile(qp.u_hover, (qp.N - 1, 1)))
+    s.con_ids = []
+    from altro_mpc_icra2021_amd import problems as P
+    for c in qp.constraints:
+        if c.kind == P.BOX:
+            s.con_ids.append(s.add_box(c.zmin, c.zmax, c.k_first, c.k_last))
+        else:
+            s.con_ids.append(s.add_affine(c.kind, c.sense, c.A, c.b, c.k_first, c.k_last))
+    s.set_opts(O.default_opts(**opts))
+    return s
+
+
+def quadruped_gpu_problem(altro, qp, x0, A, Bm, d):
+    """x0 (B, 12); A, Bm, d per instance and per knot: (B, N-1, 12, 12), (B, N-1, 12)."""
+    from altro_mpc_icra2021_amd import problems as P
+    B = x0.shape[0]
+    model = altro.LinearModel(A, Bm, d, dt=qp.dt, per_knot=True)
+    obj = altro.TrackingObjective(qp.Q, qp.R, qp.Q, np.tile(qp.x_des, (B, qp.N, 1)), np.zeros((B, qp.N - 1, qp.m)))
+    cons = altro.ConstraintList(qp.n, qp.m, qp.N)
+    for c in qp.constraints:
+        if c.kind == P.BOX:
+            bc = altro.BoundConstraint(qp.n, qp.m, u_min=c.zmin[qp.n:], u_max=c.zmax[qp.n:])
+            cons.add_constraint(bc, (c.k_first + 1, c.k_last + 1))
+        else:
+            cons.add_constraint(altro.LinearConstraint(c.A, c.b, equality=(c.sense == P.EQ)), (c.k_first + 1, c.k_last + 1))
+    return altro.Problem(model, obj, cons, x0=x0.copy(), N=qp.N, U0=np.tile(qp.u_hover, (B, qp.N - 1, 1)))
+
+
+def quadruped_condensed_qp(qp, x0, A, Bm, d):
+    """The same problem as a dense QP in U for the ADMM solver: returns (P, q, G, h, cones, X(U))."""
+    N, n, m = qp.N, qp.n, qp.m
+    nu = (N - 1) * m
+    Phi = np.zeros((N * n, n)); Gam = np.zeros((N * n, nu)); cvec = np.zeros(N * n)
+    Phi[:n] = np.eye(n)
+    for k in range(1, N):
+        Phi[k * n:(k + 1) * n] = A[k - 1] @ Phi[(k - 1) * n:k * n]
+        Gam[k * n:(k + 1) * n] = A[k - 1] @ Gam[(k - 1) * n:k * n]
+        Gam[k * n:(k + 1) * n, (k - 1) * m:k * m] += Bm[k - 1]
+        cvec[k * n:(k + 1) * n] = A[k - 1] @ cvec[(k - 1) * n:k * n] + d[k - 1]
+    wx = np.concatenate([qp.dt * qp.Q] * (N - 1) + [qp.Q])
+    wu = np.concatenate([qp.dt * qp.R] * (N - 1))
+    base = Phi @ x0 + cvec - np.tile(qp.x_des, N)
+    Pm = Gam.T @ (wx[:, None] * Gam) + np.diag(wu)
+    q = Gam.T @ (wx * base)
+    from altro_mpc_icra2021_amd import problems as P
+    rows, hs = [], []
+    for c in qp.constraints:
+        for k in range(c.k_first, min(c.k_last, N - 2) + 1):
+            if c.kind == P.BOX:
+                for j in range(m):
+                    e = np.zeros(nu); e[k * m + j] = 1.0
+                    if np.isfinite(c.zmax[n + j]): rows.append(-e); hs.append(c.zmax[n + j])
+                    if np.isfinite(c.zmin[n + j]): rows.append(e); hs.append(-c.zmin[n + j])
+            else:
+                for r in range(c.A.shape[0]):
+                    e = np.zeros(nu); e[k * m:(k + 1) * m] = -c.A[r, n:]
+                    assert not np.any(c.A[r, :n])
+                    rows.append(e); hs.append(-c.b[r])
+    G, h = np.array(rows), np.array(hs)
+    return Pm, q, G, h, [("nonneg", len(hs))], (lambda U: (Phi @ x0 + Gam @ U + cvec).reshape(N, n))

@@ -13,8 +13,8 @@ import pytest
 
 import altro_mpc_icra2021_amd as altro
 from altro_mpc_icra2021_amd import problems as P
-from helpers import (REF_OPTS, ROCKET_COLD_OPTS, ROCKET_MPC_OPTS, make_oracle, mpc_update, rocket_gpu_problem,
-                     rocket_oracle)
+from helpers import (REF_OPTS, ROCKET_COLD_OPTS, ROCKET_MPC_OPTS, make_oracle, mpc_update, quadruped_gpu_problem,
+                     quadruped_oracle, rocket_gpu_problem, rocket_oracle)
 
 pytestmark = pytest.mark.gpu
 
@@ -94,6 +94,57 @@ def test_mpc_loop_wide_kernel_sizes_match_oracle(oracle, n, m, N):
             x0 = mpc_update(orcs[b], pb, b, i)
             assert np.abs(x0 - x0g[b]).max() <= 1e-12 * max(1.0, np.abs(x0).max())
             check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+
+
+@pytest.mark.parametrize("N", [15, 40])
+def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N):
+    """Quadruped MPC (BASELINE configs[4]; Woofer/MPCControl/altro_solver.jl:40-88): n = m = 12,
+    per-knot affine dynamics re-linearised before every solve with the trot's contact mask
+    (update_dynamics_matrices!), friction pyramids + f_z box, then set_initial_state!, primal and
+    dual shift_fill!, solve!.  Every instance starts at its own gait phase and state error.
+    N = 15 is the reference's horizon (MPC.yaml:21), N = 40 BASELINE's."""
+    B, S = 6, 5
+    qp = P.gen_quadruped_problem(N=N)
+    rng = np.random.default_rng(7)
+    t0 = rng.uniform(0.0, 0.8, B)
+    x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+
+    def dyn(i):
+        D = [qp.dynamics(t0[b] + i * qp.dt) for b in range(B)]
+        return np.stack([a for a, _, _ in D]), np.stack([bm for _, bm, _ in D]), np.stack([dd for _, _, dd in D])
+
+    A, Bm, d = dyn(0)
+    sv = altro.ALTROSolver(quadruped_gpu_problem(altro, qp, x0, A, Bm, d), altro.SolverOptions(**P.QUADRUPED_OPTS))
+    assert altro.wave_cycles(sv).size == 0            # n + m = 24: the wide kernel
+    altro.solve(sv)
+    orcs = [quadruped_oracle(oracle, qp, x0[b], A[b], Bm[b], d[b], P.QUADRUPED_OPTS) for b in range(B)]
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    nact = 0
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+    for i in range(1, S + 1):
+        xn = np.zeros((B, 12))
+        for b in range(B):
+            xn[b] = orcs[b].plant_step() + 1e-3 * rng.standard_normal(12)
+        A, Bm, d = dyn(i)
+        altro.set_dynamics(sv, altro.LinearModel(A, Bm, d, dt=qp.dt, per_knot=True))
+        altro.set_initial_state(sv, xn)
+        altro.shift_fill(sv, True, True)
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            o = orcs[b]
+            o.set_dynamics(A[b], Bm[b], d[b])
+            o.set_initial_state(xn[b])
+            o.shift_fill(True, True)
+            so = o.solve()
+            check_against_oracle(st, X, U, b, o, so)
+            for c in range(5):
+                lam = altro.get_duals(sv, c)[b]
+                assert np.abs(lam.reshape(-1) - o.duals(o.con_ids[c])).max() <= RTOL * max(1.0, np.abs(o.duals(o.con_ids[c])).max())
+            fz = U[b][:, 2::3]
+            nact += int((fz < 1e-3).sum())
+    assert nact > 20      # swing legs sit on the f_z >= 0 bound: the contact switches are exercised
 
 
 def test_cold_solve_far_from_reference_matches_oracle(oracle):

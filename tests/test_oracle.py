@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from altro_mpc_icra2021_amd import problems
-from helpers import REF_OPTS, condensed_qp, make_oracle, mpc_update
+from helpers import (REF_OPTS, admm_conic_qp, condensed_qp, make_oracle, mpc_update, quadruped_condensed_qp,
+                     quadruped_oracle)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -194,3 +195,33 @@ def test_flexible_satellite_mpc_loop_warm_starts(oracle):
         err.append(np.abs(xn[:3]).max())
     assert max(its) <= 20, its
     assert err[-1] < err[0]
+
+
+def test_quadruped_ltv_friction_matches_independent_convex_solve(oracle):
+    """Quadruped MPC problem (Structs/ALTROParams.jl:32-108): per-knot affine dynamics with the
+    trot's contact switches, linearised friction pyramids, 0 <= f_z <= 133.  The oracle's converged
+    solve is held against an ADMM solution of the condensed QP (the reference compares ALTRO with
+    OSQP on this problem, osqp_solver.jl)."""
+    qp = problems.gen_quadruped_problem(N=15)
+    A, Bm, d = qp.dynamics(0.13)                 # the horizon crosses two contact switches
+    assert len({tuple(problems.trot_contacts(0.13 + k * qp.dt)) for k in range(qp.N - 1)}) >= 2
+    x0 = qp.x_des + np.array([0.02, -0.03, -0.03, 0.05, -0.04, 0.06, 0.3, -0.2, 0.1, 0.2, -0.3, 0.1])
+    tight = dict(problems.QUADRUPED_OPTS, cost_tolerance=1e-12, cost_tolerance_intermediate=1e-12,
+                 constraint_tolerance=1e-9, gradient_tolerance=1e-8, gradient_tolerance_intermediate=1e-8,
+                 penalty_scaling=10.0, iterations_outer=40, iterations=3000)
+    s = quadruped_oracle(oracle, qp, x0, A, Bm, d, tight)
+    st = s.solve()
+    assert st.status == 1, (st.status, st.iterations, st.c_max)
+    Pm, q, G, h, cones, Xof = quadruped_condensed_qp(qp, x0, A, Bm, d)
+    u, it = admm_conic_qp(Pm, q, G, h, cones, rho=0.1, iters=100000, tol=1e-10)
+    U = u.reshape(qp.N - 1, qp.m)
+    assert (np.abs(G @ u + h) < 1e-7).sum() >= 10          # friction / force limits are active
+    assert np.abs(s.controls() - U).max() < 1e-5 * max(1.0, np.abs(U).max())
+    assert np.abs(s.states() - Xof(u)).max() < 1e-6
+    # swing feet carry no force in the optimum (their columns of B_k are zero, R > 0)
+    Uo = s.controls()
+    for k in range(qp.N - 1):
+        c = problems.trot_contacts(0.13 + k * qp.dt)
+        for leg in range(4):
+            if c[leg] == 0:
+                assert np.abs(Uo[k, 3 * leg:3 * leg + 3]).max() < 1e-6
