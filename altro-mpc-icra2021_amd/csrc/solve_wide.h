@@ -116,6 +116,17 @@ __device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, in
     }
 }
 
+#ifdef ALTRO_WIDE_STAMPS
+#define WSTAMP(x) x
+__device__ __forceinline__ long long wstamp() {
+  long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#else
+#define WSTAMP(x)
+#endif
+
 struct Solver {
   const Params& P;
   const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
@@ -128,6 +139,7 @@ struct Solver {
   double mu, rho, drho;
   int dj_zero, status, iters, iters_outer;
   long long nbw, nro, ntr;
+  long long t_bw = 0, t_ro = 0, t_gemm = 0;
 
   __device__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(p.np), mp(p.mp), nz(p.n + p.m),
@@ -157,6 +169,33 @@ struct Solver {
   __device__ __forceinline__ double* Xp(int pl) const { return Xi + (size_t)pl * N * n; }
   __device__ __forceinline__ double* Up(int pl) const { return Ui + (size_t)pl * (N - 1) * m; }
 
+  // sum_j col[j * stride] * vec[j], j < cnt, with the global loads issued eight at a time (a plain
+  // accumulate loop waits a full memory round trip per term at this occupancy).  vec is an LDS
+  // vector that is zero beyond cnt up to the next multiple of 8.
+  static __device__ __forceinline__ double dot_strided(const double* col, size_t stride, const double* vec, int cnt, double acc) {
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = col[(size_t)(j0 + u < cnt ? j0 + u : cnt - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += a[u] * vec[j0 + u];
+    }
+    return acc;
+  }
+
+  // x+ = A x + B u + f for row T of knot k's dynamics, z = [x; u] in zb (padded layout)
+  __device__ __forceinline__ double next_state(int k) const {
+    double acc = fk(k)[T];
+    if (!P.ltv) {  // time-invariant: [A B] is resident in LDS (row T, odd leading dimension: no bank conflicts)
+      const double* g = G + T * ly.ldg;
+      for (int j = 0; j < n; ++j) acc += g[j] * zb[j];
+      for (int a = 0; a < m; ++a) acc += g[np + a] * zb[np + a];
+      return acc;
+    }
+    acc = dot_strided(Ak(k) + T, n, zb, n, acc);
+    return dot_strided(Bk(k) + T, n, zb + np, m, acc);
+  }
+
   // AL cost of one box-bounded element
   static __device__ __forceinline__ double lane_cost(double w, double z, double zr, double zmx, double zmn, double lhi,
                                                      double llo, double mu, bool box_on, double& viol) {
@@ -181,9 +220,8 @@ struct Solver {
   __device__ __forceinline__ double row_value(int k, int r, bool term) const {
     double v = P.bcon[(size_t)k * Pn + r];
     const double* At = P.AconT + (size_t)k * nz * Pn + r;
-    for (int c = 0; c < n; ++c) v += At[(size_t)c * Pn] * zb[c];
-    if (!term)
-      for (int a = 0; a < m; ++a) v += At[(size_t)(n + a) * Pn] * zb[np + a];
+    v = dot_strided(At, Pn, zb, n, v);
+    if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
     return v;
   }
 
@@ -238,8 +276,7 @@ struct Solver {
         double acc = Us[(size_t)k * m + T];
         if (!open) {
           acc += alpha * dgi[(size_t)k * m + T];
-          const double* Kk = Kgi + (size_t)k * n * m + T;
-          for (int j = 0; j < n; ++j) acc += Kk[(size_t)j * m] * dxv[j];
+          acc = dot_strided(Kgi + (size_t)k * n * m + T, m, dxv, n, acc);
           Ud[(size_t)k * m + T] = acc;
         }
         uv = acc;
@@ -249,13 +286,7 @@ struct Solver {
       eval_knot(k, false, xb, uv, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
       double xn = 0.0;
-      if (T < n) {
-        const double *A_ = Ak(k) + T, *B_ = Bk(k) + T;
-        double acc = fk(k)[T];
-        for (int j = 0; j < n; ++j) acc += A_[(size_t)j * n] * zb[j];
-        for (int a = 0; a < m; ++a) acc += B_[(size_t)a * n] * zb[np + a];
-        xn = acc;
-      }
+      if (T < n) xn = next_state(k);
       __syncthreads();
       xb = xn;
     }
@@ -380,7 +411,6 @@ struct Solver {
     if (Pn > 0) gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
     dV1 = 0.0;
     dV2 = 0.0;
-    if (!P.ltv) load_dyn(0);
     __syncthreads();
     for (int k = N - 2; k >= 0; --k) {
       if (P.ltv) load_dyn(k);
@@ -391,12 +421,14 @@ struct Solver {
         for (int i = 0; i < n; ++i) acc += G[i * ldg + c] * sv[i];
         qv[c] = acc;
       }
+      WSTAMP(const long long tg = wstamp();)
       gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
       __syncthreads();
       gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
       gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
       gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
       __syncthreads();
+      WSTAMP(t_gemm += wstamp() - tg;)
       if (T < n) S[T * lds + T] += hz[T];
       if (T < m) {
         Huu[T * ldu + T] += hz[np + T];
@@ -512,7 +544,9 @@ struct Solver {
     rho = o.bp_reg_initial;
     drho = 0.0;
     dj_zero = 0;
+    WSTAMP(const long long ts0 = wstamp();)
     RollOut r0 = rollout(true, 0.0);
+    WSTAMP(t_ro += wstamp() - ts0;)
     nro++;
     if (r0.limit) {
       status = ALTRO_STATE_LIMIT;
@@ -525,7 +559,9 @@ struct Solver {
       double dV1, dV2;
       bool gave_up = false;
       while (true) {  // regularisation restarts
+        WSTAMP(const long long ts = wstamp();)
         const bool fail = backward(dV1, dV2);
+        WSTAMP(t_bw += wstamp() - ts;)
         nbw++;
         __syncthreads();
         if (!fail) break;
@@ -549,7 +585,9 @@ struct Solver {
           rho += o.bp_reg_fp;
           break;
         }
+        WSTAMP(const long long ts = wstamp();)
         const RollOut r = rollout(false, alpha);
+        WSTAMP(t_ro += wstamp() - ts;)
         if (ls == 0) nro++; else ntr++;
         if (r.limit) { ls++; alpha *= 0.5; continue; }
         J = r.J;
@@ -643,13 +681,7 @@ struct Solver {
     if (T < m) zb[np + T] = Us[T];
     __syncthreads();
     double xn = 0.0;
-    if (T < n) {
-      const double *A_ = Ak(0) + T, *B_ = Bk(0) + T;
-      double acc = fk(0)[T];
-      for (int j = 0; j < n; ++j) acc += A_[(size_t)j * n] * zb[j];
-      for (int a = 0; a < m; ++a) acc += B_[(size_t)a * n] * zb[np + a];
-      xn = acc;
-    }
+    if (T < n) xn = next_state(0);
     double nrm = 1.0;
     if (P.noise_mode == 0) {
       nrm = wave_max(T < n ? fabs(xn) : 0.0);
@@ -714,6 +746,10 @@ struct Solver {
     kref = P.kref;
     nbw = nro = ntr = 0;
     long long nsolve = 0, nit = 0, nok = 0;
+    if (!P.ltv) {
+      load_dyn(0);
+      __syncthreads();
+    }
     const int steps = mpc ? nsteps : 1;
     for (int s = 0; s < steps; ++s) {
       if (mpc) {
@@ -731,7 +767,13 @@ struct Solver {
       P.mu[inst] = mu;
       P.n_backward[inst] += nbw;
       P.n_rollout[inst] += nro;
+#ifdef ALTRO_WIDE_STAMPS
+      P.n_trials[inst] = t_gemm;  // diagnostic build: the three counters carry cycle counts
+      P.n_backward[inst] = t_bw;
+      P.n_rollout[inst] = t_ro;
+#else
       P.n_trials[inst] += ntr;
+#endif
       P.n_solves[inst] += nsolve;
       P.n_iters[inst] += nit;
       P.n_ok[inst] += nok;
