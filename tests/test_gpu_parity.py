@@ -580,6 +580,68 @@ def test_grasp_cold_solve_matches_oracle_and_reference_fixture(oracle):
     assert np.abs(U[0, :, 1:3] - F1).max() < 1e-6 and np.abs(U[0, :, 4:6] - F2).max() < 1e-6
 
 
+def test_grasp_mpc_loop_with_per_step_constraint_updates_matches_oracle(oracle):
+    """run_grasp_mpc (grasp_mpc.jl:8-104) with mpc_update! (grasp_mpc_helpers.jl:1-55): every MPC
+    step takes x0 from the plant with 1 % noise, retargets the tracking cost, shifts the primal
+    trajectory, REWRITES the per-knot data of all four stage constraints (torque balance, normal
+    force, both friction cones) for the shifted window, shifts the duals and solves.  Options of
+    grasp_benchmark.jl:26-34 (reset_duals stays true), tracking weights :79-80."""
+    B, Nc, Nm, S = 4, 61, 21, 6
+    gp = P.gen_grasp_problem(N=Nc, tf=6.0)
+    cold_opts = dict(cost_tolerance=1e-6, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-6,
+                     iterations=5000, iterations_outer=60, iterations_inner=300)           # grasp_benchmark.jl:19-25
+    cold = rocket_oracle(oracle, gp, gp.x0, cold_opts)
+    assert cold.solve().status == 1
+    Xt, Ut = cold.states(), cold.controls()                                                  # Z_track
+    mpc_opts = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-3, constraint_tolerance=1e-4,
+                    penalty_initial=10000.0, penalty_scaling=100.0)
+
+    def window(k0):
+        """stage constraints of knots k0 .. k0+Nm-1 of the long problem; the goal is dropped (mpc.jl:33-40)"""
+        out = []
+        for c in gp.constraints[1:]:
+            out.append(P.ConstraintSpec(c.kind, c.sense, 0, Nm - 2, A=c.A[k0:k0 + Nm - 1].copy(), b=c.b[k0:k0 + Nm - 1].copy()))
+        return out
+
+    import copy
+    tp = copy.copy(gp)
+    tp.N, tp.Q, tp.R, tp.Qf = Nm, np.full(6, 1e3), np.full(6, 1.0), np.full(6, 10.0)
+    tp.constraints = window(0)
+    x0 = np.tile(Xt[0], (B, 1))
+    Xr, Ur = np.tile(Xt[:Nm], (B, 1, 1)), np.tile(Ut[:Nm - 1], (B, 1, 1))
+    sv = altro.ALTROSolver(rocket_gpu_problem(altro, tp, x0, Xr, Ur, U0=Ur.copy()), altro.SolverOptions(**mpc_opts))
+    altro.solve(sv)
+    orcs = [rocket_oracle(oracle, tp, x0[b], mpc_opts, Xr[b], Ur[b], U0=Ur[b]) for b in range(B)]
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+    rng = np.random.default_rng(9)
+    for i in range(1, S + 1):
+        cons = window(i)
+        x0n = np.zeros((B, 6))
+        for b in range(B):
+            xn = orcs[b].plant_step()
+            x0n[b] = xn + rng.standard_normal(6) * np.abs(xn).max() / 100.0
+            orcs[b].set_initial_state(x0n[b])
+            orcs[b].set_reference(Xt[i:i + Nm], Ut[i:i + Nm - 1])
+            orcs[b].shift_fill(True, False)
+            for ci, c in enumerate(cons):
+                orcs[b].update_constraint_data(orcs[b].con_ids[ci], c.A, c.b)
+            orcs[b].shift_fill(False, True)
+        altro.set_initial_state(sv, x0n)
+        altro.update_trajectory(sv, np.tile(Xt[i:i + Nm], (B, 1, 1)), np.tile(Ut[i:i + Nm - 1], (B, 1, 1)))
+        altro.shift_fill(sv, True, False)
+        for ci, c in enumerate(cons):
+            altro.update_constraint_data(sv, ci, c.A, c.b)
+        altro.shift_fill(sv, False, True)
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            so = orcs[b].solve()
+            assert so.status == 1
+            check_against_oracle(st, X, U, b, orcs[b], so)
+
+
 def test_update_constraint_data_is_seen_by_the_next_solve(oracle):
     """grasp_mpc_helpers.jl:46-55 mutates the per-knot constraint matrices in place between
     solves; altro_batch_update_constraint_data is that mutation."""
