@@ -482,6 +482,10 @@ struct Solver {
     const int cur = rs->cur, kref = rs->kref;
     const unsigned zs = plane(cur);
     const unsigned zd = OPEN ? (take ? plane(cur) : trash_z() - 0u) : plane(cur ^ 1);
+    // Stores of rows that sit a phase out go to trash rows.  The select is made on the KNOT INDEX (one
+    // v_cndmask); selecting between two computed addresses made hipcc emit divergent branches with
+    // scratch reloads and s_waitcnt vmcnt(0) inside the loop, which serialises the prefetch ring.
+    const bool wl = OPEN && shift && take && bounded;
     const int N = P.N;
     double grow[NZ];
     sfor<0, NZ>([&](auto c) {
@@ -526,10 +530,10 @@ struct Solver {
       double zb;
       if constexpr (OPEN) {
         zb = is_x ? xb : in.z;
-        stg(P.Z, take ? (zd + at(k)) : trash_z(), zb);
-        const bool wl = wr_l & bounded;
-        stg(P.Lb, wl ? lb_at(k, 0) : trash_l(0), lhi);
-        stg(P.Lb, wl ? lb_at(k, 1) : trash_l(1), llo);
+        stg(P.Z, at(take ? cur * N + k : 2 * N), zb);
+        const int kl_ = wl ? k : P.N;  // knot N of Lb is the trash row
+        stg(P.Lb, lb_at(kl_, 0), lhi);
+        stg(P.Lb, lb_at(kl_, 1), llo);
       } else {
         // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
         const double dx = is_x ? (xb - in.z) : 0.0;
@@ -562,7 +566,7 @@ struct Solver {
         const ConeEval e = cone_eval<false>(v, act ? in.lc : 0.0, mu, ck.cm, act, dmax, so2);
         Jacc += e.cost;
         viol = fmax(viol, e.viol);
-        if constexpr (OPEN) stg(P.Lc, (wr_l & act) ? at(k) : at(P.N), in.lc);
+        if constexpr (OPEN) stg(P.Lc, at((wr_l & act) ? k : P.N), in.lc);
       }
       const double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
       limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
@@ -611,7 +615,7 @@ struct Solver {
     {  // terminal knot: state only
       const bool bx = box_at(kt);
       const double zb = is_x ? xb : 0.0;
-      if constexpr (OPEN) stg(P.Z, take ? (zd + at(kt)) : trash_z(), zb);
+      if constexpr (OPEN) stg(P.Z, at(take ? cur * N + kt : 2 * N), zb);
       else stg(P.Z, zd + at(kt), zb);
       Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
       if constexpr (CONES) {
@@ -782,7 +786,7 @@ struct Solver {
         const int k = k0 + Q;
         const bool on = (k >= N - 1) ? is_x : (is_x | is_u);
         const double zb = on ? __builtin_fma(alpha, zz1[Q] - z[Q], z[Q]) : 0.0;
-        stg(P.Z, (doit & (k < N)) ? (z1 + at(imin(k, N - 1))) : trash_z(), zb);
+        stg(P.Z, at((doit & (k < N)) ? (cur ^ 1) * N + imin(k, N - 1) : 2 * N), zb);
       });
     }
   }
@@ -1028,8 +1032,8 @@ struct Solver {
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       const double nhi = fmin(fmax(lhi + mu * (z - lc.zmax), 0.0), dmax);
       const double nlo = fmin(fmax(llo + mu * (lc.zmin - z), 0.0), dmax);
-      stg(P.Lb, (upd & on & lc.has_hi) ? lb_at(k, 0) : trash_l(0), nhi);
-      stg(P.Lb, (upd & on & lc.has_lo) ? lb_at(k, 1) : trash_l(1), nlo);
+      stg(P.Lb, lb_at((upd & on & lc.has_hi) ? k : P.N, 0), nhi);
+      stg(P.Lb, lb_at((upd & on & lc.has_lo) ? k : P.N, 1), nlo);
     }
     if constexpr (CONES) {  // dual_update! of the generic rows: eq / ineq clamp, SOC projection
       const bool so2 = P.o.soc_second_order != 0;
@@ -1044,7 +1048,7 @@ struct Solver {
         const double v = con_value(live ? z : 0.0, ck.arow, ck.brow);
         const ConeEval e = cone_eval<false>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
         const bool row_on = act & ((cm.type == CT_SOC) ? (cm.pos < cm.p) : (cm.type != CT_NONE));
-        stg(P.Lc, (upd & row_on) ? at(k) : at(P.N), e.lam_new);
+        stg(P.Lc, at((upd & row_on) ? k : P.N), e.lam_new);
       }
     }
   }
@@ -1118,11 +1122,11 @@ struct Solver {
           if (mpc && wave_any(go)) plant_step(go, first_step + stp);
           if (o.reset_duals && wave_any(go)) {  // initialize!: lambda <- 0
             for (int k = P.box_k0; k <= P.box_k1; ++k) {
-              stg(P.Lb, (go & bounded) ? lb_at(k, 0) : trash_l(0), 0.0);
-              stg(P.Lb, (go & bounded) ? lb_at(k, 1) : trash_l(1), 0.0);
+              stg(P.Lb, lb_at((go & bounded) ? k : P.N, 0), 0.0);
+              stg(P.Lb, lb_at((go & bounded) ? k : P.N, 1), 0.0);
             }
             if constexpr (CONES) {
-              for (int k = 0; k < P.N; ++k) stg(P.Lc, go ? at(k) : at(P.N), 0.0);
+              for (int k = 0; k < P.N; ++k) stg(P.Lc, at(go ? k : P.N), 0.0);
             }
           }
           if (begin) {
