@@ -83,6 +83,15 @@ __host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
   return L;
 }
 
+// One wave per block: LDS instructions of a wave execute in issue order, so a cross-lane hand-over
+// through LDS only needs the COMPILER to keep the order.  __syncthreads() would also drain vmcnt(0),
+// i.e. wait for every outstanding global store of the knot, three times per knot.
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -93,27 +102,56 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 __device__ __forceinline__ bool wave_any(bool f) { return __ballot(f) != 0ull; }
 
-// C[M x Nn] (ldc) = (ACC ? C : 0) + scale * sum_k AT[k][i] B[k][j];  M, Nn multiples of 16, K of 4
+// C[M x Nn] (ldc) = (ACC ? C : 0) + scale * sum_k AT[k][i] B[k][j];  M, Nn multiples of 16, K of 4.
+// A strip of NT output tiles shares the A fragment; the fragments of k-step s+1 are requested before
+// the MFMAs of step s issue, so the matrix pipe sees NT independent accumulator chains and the LDS
+// latency is off the critical path (one tile at a time ran at ~250 cycles per MFMA instead of 64).
+template <bool ACC, int NT>
+__device__ __forceinline__ void gemm_strip(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int i0,
+                                           int j0, int K, double scale) {
+  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
+  d4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const double* ap = AT + q * lda + i0 + r16;
+  const double* bp = Bq + q * ldb + j0 + r16;
+  double a = ap[0], b[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b[t] = bp[16 * t];
+  for (int k0 = 4; k0 <= K; k0 += 4) {
+    double an, bn[NT];
+    const int kk = k0 < K ? k0 : 0;  // the last step re-reads step 0 (harmless): the loop body stays branch-free
+    an = ap[kk * lda];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bn[t] = bp[kk * ldb + 16 * t];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+    a = an;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = bn[t];
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* c = C + (i0 + q + 4 * r) * ldc + j0 + 16 * t + r16;
+      const double v = scale * acc[t][r];
+      *c = ACC ? (*c + v) : v;
+    }
+}
+
 template <bool ACC>
 __device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int M,
                                         int Nn, int K, double scale = 1.0) {
-  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
-  for (int i0 = 0; i0 < M; i0 += 16)
-    for (int j0 = 0; j0 < Nn; j0 += 16) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const double a = AT[(k0 + q) * lda + i0 + r16];
-        const double b = Bq[(k0 + q) * ldb + j0 + r16];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      }
-      // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* c = C + (i0 + q + 4 * r) * ldc + j0 + r16;
-        const double v = scale * acc[r];
-        *c = ACC ? (*c + v) : v;
-      }
-    }
+  for (int i0 = 0; i0 < M; i0 += 16) {
+    int j0 = 0;
+    for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+    const int rem = (Nn - j0) >> 4;
+    if (rem == 3) gemm_strip<ACC, 3>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+    else if (rem == 2) gemm_strip<ACC, 2>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+    else if (rem == 1) gemm_strip<ACC, 1>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+  }
 }
 
 #ifdef ALTRO_WIDE_STAMPS
@@ -270,7 +308,7 @@ struct Solver {
         if (!open) dxv[T] = xb - Xs[(size_t)k * n + T];
         Xd[(size_t)k * n + T] = xb;
       }
-      __syncthreads();
+      wsync();
       double uv = 0.0;
       if (T < m) {
         double acc = Us[(size_t)k * m + T];
@@ -282,22 +320,22 @@ struct Solver {
         uv = acc;
         zb[np + T] = acc;
       }
-      __syncthreads();
+      wsync();
       eval_knot(k, false, xb, uv, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
       double xn = 0.0;
       if (T < n) xn = next_state(k);
-      __syncthreads();
+      wsync();
       xb = xn;
     }
     if (T < n) {
       zb[T] = xb;
       Xd[(size_t)(N - 1) * n + T] = xb;
     }
-    __syncthreads();
+    wsync();
     eval_knot(N - 1, true, xb, 0.0, J, viol);
     lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value));
-    __syncthreads();
+    __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
@@ -362,7 +400,7 @@ struct Solver {
       qz[np + T] = q;
       hz[np + T] = h;
     }
-    __syncthreads();
+    wsync();
     if (Pn > 0) {
       if (T < Pp) {
         double g = 0.0, D = 0.0;
@@ -378,7 +416,7 @@ struct Solver {
         gr[T] = g;
         Dr[T] = D;
       }
-      __syncthreads();
+      wsync();
       const double* At = P.AconT + (size_t)k * nz * Pn;
       for (int e = T; e < nz * Pn; e += 64) {
         const int j = e / Pn, r = e - j * Pn;
@@ -387,13 +425,13 @@ struct Solver {
         Ac[r * ly.ldg + c] = v;
         DA[r * ly.ldg + c] = Dr[r] * v;
       }
-      __syncthreads();
+      wsync();
       for (int c = T; c < nzp; c += 64) {
         double acc = 0.0;
         for (int r = 0; r < Pn; ++r) acc += Ac[r * ly.ldg + c] * gr[r];
         qz[c] += acc;
       }
-      __syncthreads();
+      wsync();
     }
   }
 
@@ -401,17 +439,17 @@ struct Solver {
   __device__ bool backward(double& dV1, double& dV2) {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
-    __syncthreads();
+    wsync();
     expansion(N - 1, true);
     if (T < n) {
       S[T * lds + T] = hz[T];
       sv[T] = qz[T];
     }
-    __syncthreads();
+    wsync();
     if (Pn > 0) gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
     dV1 = 0.0;
     dV2 = 0.0;
-    __syncthreads();
+    wsync();
     for (int k = N - 2; k >= 0; --k) {
       if (P.ltv) load_dyn(k);
       expansion(k, false);  // ends with a barrier
@@ -423,38 +461,38 @@ struct Solver {
       }
       WSTAMP(const long long tg = wstamp();)
       gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
-      __syncthreads();
+      wsync();
       gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
       gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
       gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
-      __syncthreads();
+      wsync();
       WSTAMP(t_gemm += wstamp() - tg;)
       if (T < n) S[T * lds + T] += hz[T];
       if (T < m) {
         Huu[T * ldu + T] += hz[np + T];
         Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
       }
-      __syncthreads();
+      wsync();
       if (Pn > 0) {
         gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
         gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
         gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
-        __syncthreads();
+        wsync();
       }
       for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];
       if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
-      __syncthreads();
+      wsync();
       // Quu_reg = L D L' in place (unit L below the diagonal, D on it)
       for (int j = 0; j < m; ++j) {
         const double dj = Huu[j * ldu + j];
         if (!(dj > 0.0)) return true;  // wave-uniform
         if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
-        __syncthreads();
+        wsync();
         if (T > j && T < m) {
           const double li = Huu[T * ldu + j];
           for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
         }
-        __syncthreads();
+        wsync();
       }
       // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
       for (int c = T; c <= np; c += 64) {
@@ -473,7 +511,7 @@ struct Solver {
           for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
         }
       }
-      __syncthreads();
+      wsync();
       // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
       {
         double t1 = 0.0, dd = 0.0;
@@ -495,7 +533,7 @@ struct Solver {
         for (int a = 0; a < m; ++a) acc += (Hux[a * ldh + T] - rho * Kl[a * ldh + T]) * Kl[a * ldh + np];
         sv[T] = acc;
       }
-      __syncthreads();
+      wsync();
       for (int e = T; e < n * n; e += 64) {  // S <- (S + S')/2
         const int i = e / n, j = e - i * n;
         if (i > j) {
@@ -510,7 +548,7 @@ struct Solver {
         Kk[e] = Kl[a * ldh + j];
       }
       if (T < m) dgi[(size_t)k * m + T] = Kl[T * ldh + np];
-      __syncthreads();
+      wsync();
     }
     return false;
   }
@@ -563,7 +601,7 @@ struct Solver {
         const bool fail = backward(dV1, dV2);
         WSTAMP(t_bw += wstamp() - ts;)
         nbw++;
-        __syncthreads();
+        __syncthreads();  // phase end: gains written to global memory are read by other lanes in the rollout
         if (!fail) break;
         if (rho >= o.bp_reg_max) { gave_up = true; break; }
         reg_update(true);
@@ -627,7 +665,7 @@ struct Solver {
       double xv = 0.0, uv = 0.0;
       if (T < n) { xv = Xs[(size_t)k * n + T]; zb[T] = xv; }
       if (T < m) { uv = term ? 0.0 : Us[(size_t)k * m + T]; zb[np + T] = uv; }
-      __syncthreads();
+      wsync();
       if (box_at(k)) {
         for (int pass = 0; pass < 2; ++pass) {
           const bool on = pass == 0 ? (T < n) : (T < m && !term);
@@ -652,7 +690,7 @@ struct Solver {
           *l = fmin(fmax(v, ct == 1 ? -dmax : 0.0), dmax);
         }
       }
-      __syncthreads();
+      wsync();
     }
   }
 
@@ -670,7 +708,7 @@ struct Solver {
       if (T < Pn)
         for (int k = P.rowk0[T]; k < P.rowk1[T]; ++k) Lci[(size_t)k * Pn + T] = Lci[(size_t)(k + 1) * Pn + T];
     }
-    __syncthreads();
+    wsync();
   }
 
   // plant step of the device MPC loop: x0 <- A x_1 + B u_1 + f + noise (time-invariant dynamics only)
@@ -679,7 +717,7 @@ struct Solver {
     const double* Us = Up(cur);
     if (T < n) zb[T] = Xs[T];
     if (T < m) zb[np + T] = Us[T];
-    __syncthreads();
+    wsync();
     double xn = 0.0;
     if (T < n) xn = next_state(0);
     double nrm = 1.0;
@@ -694,7 +732,7 @@ struct Solver {
       const double nzv = P.noise ? P.noise[((size_t)step * P.B + inst) * n + T] : 0.0;
       x0i[T] = xn + nzv * nrm * P.noise_w[T];
     }
-    __syncthreads();
+    wsync();
   }
 
   // solve!(::ALTROSolver) (oracle orc_solve)
@@ -711,7 +749,7 @@ struct Solver {
     status = ALTRO_UNSOLVED;
     iters = 0;
     iters_outer = 0;
-    __syncthreads();
+    __syncthreads();  // the zeroed duals are read by other lanes
     double J = 0.0, cmax = 0.0;
     if (!has_con) {
       J = ilqr(o.cost_tolerance, o.gradient_tolerance, cmax);
@@ -748,7 +786,7 @@ struct Solver {
     long long nsolve = 0, nit = 0, nok = 0;
     if (!P.ltv) {
       load_dyn(0);
-      __syncthreads();
+      wsync();
     }
     const int steps = mpc ? nsteps : 1;
     for (int s = 0; s < steps; ++s) {
