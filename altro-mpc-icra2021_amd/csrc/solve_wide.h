@@ -177,9 +177,9 @@ struct Solver {
   double mu, rho, drho;
   int dj_zero, status, iters, iters_outer;
   long long nbw, nro, ntr;
-  long long t_bw = 0, t_ro = 0, t_gemm = 0;
+  long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
 
-  __device__ Solver(const Params& p, double* lds)
+  __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(p.np), mp(p.mp), nz(p.n + p.m),
         nzp(p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(p.n, p.m, p.Pn)) {
     G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
@@ -221,14 +221,27 @@ struct Solver {
     return acc;
   }
 
+  // sum_{j < cnt} a[j * sa] * b[j * sb] for LDS operands, cnt a multiple of 8 (the padded tails are
+  // zero): all sixteen reads of a chunk are issued before the first FMA needs one.
+  static __device__ __forceinline__ double dot_lds(const double* a, int sa, const double* b, int sb, int cnt, double acc) {
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+      double x[8], y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        x[u] = a[(j0 + u) * sa];
+        y[u] = b[(j0 + u) * sb];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += x[u] * y[u];
+    }
+    return acc;
+  }
+
   // x+ = A x + B u + f for row T of knot k's dynamics, z = [x; u] in zb (padded layout)
   __device__ __forceinline__ double next_state(int k) const {
     double acc = fk(k)[T];
     if (!P.ltv) {  // time-invariant: [A B] is resident in LDS (row T, odd leading dimension: no bank conflicts)
-      const double* g = G + T * ly.ldg;
-      for (int j = 0; j < n; ++j) acc += g[j] * zb[j];
-      for (int a = 0; a < m; ++a) acc += g[np + a] * zb[np + a];
-      return acc;
+      return dot_lds(G + T * ly.ldg, 1, zb, 1, nzp, acc);  // pads of G and zb are zero
     }
     acc = dot_strided(Ak(k) + T, n, zb, n, acc);
     return dot_strided(Bk(k) + T, n, zb + np, m, acc);
@@ -264,7 +277,7 @@ struct Solver {
   }
 
   // cost!(obj, z_k) + max_violation of knot k; zb holds [x; u] of the knot (synchronised)
-  __device__ void eval_knot(int k, bool term, double xv, double uv, double& J, double& viol) const {
+  __device__ __forceinline__ void eval_knot(int k, bool term, double xv, double uv, double& J, double& viol) const {
     const bool bx = box_at(k);
     if (T < n) {
       const double lhi = bx ? Lbi[((size_t)k * 2 + 0) * nz + T] : 0.0, llo = bx ? Lbi[((size_t)k * 2 + 1) * nz + T] : 0.0;
@@ -294,7 +307,7 @@ struct Solver {
 
   // rollout!(solver[, alpha]): open loop in place on plane cur, or closed loop from plane cur into
   // plane cur^1 (oracle rollout_open / rollout_alpha), fused with cost! and max_violation
-  __device__ RollOut rollout(bool open, double alpha) {
+  __device__ __forceinline__ RollOut rollout(bool open, double alpha) {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     double* Xd = open ? Xp(cur) : Xp(cur ^ 1);
@@ -303,12 +316,14 @@ struct Solver {
     bool lim = false;
     double xb = T < n ? x0i[T] : 0.0;
     for (int k = 0; k < N - 1; ++k) {
+      WSTAMP(const long long s0 = wstamp();)
       if (T < n) {
         zb[T] = xb;
         if (!open) dxv[T] = xb - Xs[(size_t)k * n + T];
         Xd[(size_t)k * n + T] = xb;
       }
       wsync();
+      WSTAMP(const long long s1 = wstamp(); t_a += s1 - s0;)
       double uv = 0.0;
       if (T < m) {
         double acc = Us[(size_t)k * m + T];
@@ -321,11 +336,14 @@ struct Solver {
         zb[np + T] = acc;
       }
       wsync();
+      WSTAMP(const long long s2 = wstamp(); t_b += s2 - s1;)
       eval_knot(k, false, xb, uv, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
+      WSTAMP(const long long s3 = wstamp(); t_c += s3 - s2;)
       double xn = 0.0;
       if (T < n) xn = next_state(k);
       wsync();
+      WSTAMP(t_d += wstamp() - s3;)
       xb = xn;
     }
     if (T < n) {
@@ -343,7 +361,7 @@ struct Solver {
     return r;
   }
 
-  __device__ void load_dyn(int k) {
+  __device__ __forceinline__ void load_dyn(int k) {
     const double *A_ = Ak(k), *B_ = Bk(k);
     for (int e = T; e < n * n; e += 64) {
       const int j = e / n, i = e - j * n;
@@ -373,7 +391,7 @@ struct Solver {
 
   // cost_expansion! at knot k of plane cur: gradient qz, Hessian diagonal hz (padded z layout), and
   // for the generic rows the tables Ac, DA = diag(I_mu) Ac with A'g already added to qz
-  __device__ void expansion(int k, bool term) {
+  __device__ __forceinline__ void expansion(int k, bool term) {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     const bool bx = box_at(k);
@@ -436,7 +454,7 @@ struct Solver {
   }
 
   // backwardpass! (oracle backward_pass).  Returns true if a pivot of Quu + rho I was not positive.
-  __device__ bool backward(double& dV1, double& dV2) {
+  __device__ __forceinline__ bool backward(double& dV1, double& dV2) {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
@@ -454,11 +472,7 @@ struct Solver {
       if (P.ltv) load_dyn(k);
       expansion(k, false);  // ends with a barrier
       // Q_z = l_z + [A B]' s
-      for (int c = T; c < nzp; c += 64) {
-        double acc = qz[c];
-        for (int i = 0; i < n; ++i) acc += G[i * ldg + c] * sv[i];
-        qv[c] = acc;
-      }
+      for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
       WSTAMP(const long long tg = wstamp();)
       gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
       wsync();
@@ -529,8 +543,8 @@ struct Solver {
       gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
       if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
       if (T < n) {
-        double acc = qv[T];
-        for (int a = 0; a < m; ++a) acc += (Hux[a * ldh + T] - rho * Kl[a * ldh + T]) * Kl[a * ldh + np];
+        double acc = dot_lds(Hux + T, ldh, Kl + np, ldh, mp, qv[T]);  // rows >= m are zero
+        if (rho != 0.0) acc -= rho * dot_lds(Kl + T, ldh, Kl + np, ldh, mp, 0.0);
         sv[T] = acc;
       }
       wsync();
@@ -553,7 +567,7 @@ struct Solver {
     return false;
   }
 
-  __device__ void reg_update(bool increase) {
+  __device__ __forceinline__ void reg_update(bool increase) {
     const altro_opts& o = P.o;
     if (increase) {
       drho = fmax(drho * o.bp_reg_increase_factor, o.bp_reg_increase_factor);
@@ -565,7 +579,7 @@ struct Solver {
   }
 
   // gradient_todorov! on plane cur
-  __device__ double todorov() const {
+  __device__ __forceinline__ double todorov() const {
     const double* Us = Up(cur);
     double acc = 0.0;
     for (int k = 0; k < N - 1; ++k) {
@@ -577,7 +591,7 @@ struct Solver {
   }
 
   // solve!(::iLQRSolver) (oracle ilqr_solve); returns the final cost, cmax by reference
-  __device__ double ilqr(double cost_tol, double grad_tol, double& cmax) {
+  __device__ __forceinline__ double ilqr(double cost_tol, double grad_tol, double& cmax) {
     const altro_opts& o = P.o;
     rho = o.bp_reg_initial;
     drho = 0.0;
@@ -656,7 +670,7 @@ struct Solver {
   }
 
   // dual_update! on plane cur (the penalty is scaled by the caller)
-  __device__ void dual_update() {
+  __device__ __forceinline__ void dual_update() {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     const double dmax = P.o.dual_max;
@@ -695,7 +709,7 @@ struct Solver {
   }
 
   // RD.shift_fill!(Z) and Altro.shift_fill!(conSet) on plane cur (oracle orc_shift_fill)
-  __device__ void shift(bool primal, bool dual) {
+  __device__ __forceinline__ void shift(bool primal, bool dual) {
     if (primal) {
       double* Xs = Xp(cur);
       double* Us = Up(cur);
@@ -712,7 +726,7 @@ struct Solver {
   }
 
   // plant step of the device MPC loop: x0 <- A x_1 + B u_1 + f + noise (time-invariant dynamics only)
-  __device__ void plant_step(int step) {
+  __device__ __forceinline__ void plant_step(int step) {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     if (T < n) zb[T] = Xs[T];
@@ -736,7 +750,7 @@ struct Solver {
   }
 
   // solve!(::ALTROSolver) (oracle orc_solve)
-  __device__ void solve_one() {
+  __device__ __forceinline__ void solve_one() {
     const altro_opts& o = P.o;
     const double mu0 = (o.penalty_initial != o.penalty_initial) ? 1.0 : o.penalty_initial;
     const double phi = (o.penalty_scaling != o.penalty_scaling) ? 10.0 : o.penalty_scaling;
@@ -778,7 +792,7 @@ struct Solver {
     }
   }
 
-  __device__ void run(int mpc, int first_step, int nsteps) {
+  __device__ __forceinline__ void run(int mpc, int first_step, int nsteps) {
     cur = P.cur[inst];
     mu = P.mu[inst];
     kref = P.kref;
@@ -807,6 +821,10 @@ struct Solver {
       P.n_rollout[inst] += nro;
 #ifdef ALTRO_WIDE_STAMPS
       P.n_trials[inst] = t_gemm;  // diagnostic build: the three counters carry cycle counts
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 12] = (double)t_a;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 13] = (double)t_b;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 14] = (double)t_c;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 15] = (double)t_d;
       P.n_backward[inst] = t_bw;
       P.n_rollout[inst] = t_ro;
 #else
