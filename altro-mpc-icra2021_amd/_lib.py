@@ -66,7 +66,10 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     subprocess.check_call(["python3", os.path.join(CSRC, "gen_dpp_blocks.py"), os.path.join(CSRC, "dpp_blocks.inc")])
+    # -amdgpu-mfma-vgpr-form: keep the FP64 MFMA accumulators of solve_wide.h in VGPRs; without it hipcc
+    # (ROCm 7.2) shuttles them through AGPRs around every MFMA of the k loop (64 v_accvgpr moves per step)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            "-o", LIB_PATH, os.path.join(CSRC, "altro_batch.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -106,15 +106,16 @@ __device__ __forceinline__ bool wave_any(bool f) { return __ballot(f) != 0ull; }
 // A strip of NT output tiles shares the A fragment; the fragments of k-step s+1 are requested before
 // the MFMAs of step s issue, so the matrix pipe sees NT independent accumulator chains and the LDS
 // latency is off the critical path (one tile at a time ran at ~250 cycles per MFMA instead of 64).
+typedef __attribute__((address_space(3))) double lds_d;
+
+// Built with -mllvm -amdgpu-mfma-vgpr-form=1 (see _lib.py): by default hipcc (ROCm 7.2) put the
+// accumulators in AGPRs but carried them through the k loop in VGPRs, i.e. 64 v_accvgpr moves
+// around the 4 MFMAs of every k-step.  Pointers are typed as LDS so the loads are ds_read.
 template <bool ACC, int NT>
-__device__ __forceinline__ void gemm_strip(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int i0,
-                                           int j0, int K, double scale) {
-  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
+__device__ __forceinline__ void gemm_strip(lds_d* C, int ldc, const lds_d* ap, int lda, const lds_d* bp, int ldb, int K, double scale) {
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-  const double* ap = AT + q * lda + i0 + r16;
-  const double* bp = Bq + q * ldb + j0 + r16;
   double a = ap[0], b[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) b[t] = bp[16 * t];
@@ -130,12 +131,13 @@ __device__ __forceinline__ void gemm_strip(double* C, int ldc, const double* AT,
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = bn[t];
   }
-  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg; C already points at
+  // (row lane >> 4, column lane & 15) of the strip
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double* c = C + (i0 + q + 4 * r) * ldc + j0 + 16 * t + r16;
+      lds_d* c = C + 4 * r * ldc + 16 * t;
       const double v = scale * acc[t][r];
       *c = ACC ? (*c + v) : v;
     }
@@ -144,13 +146,17 @@ __device__ __forceinline__ void gemm_strip(double* C, int ldc, const double* AT,
 template <bool ACC>
 __device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int M,
                                         int Nn, int K, double scale = 1.0) {
+  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
+  lds_d* Cl = (lds_d*)C + q * ldc + r16;
+  const lds_d* Al = (const lds_d*)AT + q * lda + r16;
+  const lds_d* Bl = (const lds_d*)Bq + q * ldb + r16;
   for (int i0 = 0; i0 < M; i0 += 16) {
     int j0 = 0;
-    for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+    for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
     const int rem = (Nn - j0) >> 4;
-    if (rem == 3) gemm_strip<ACC, 3>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
-    else if (rem == 2) gemm_strip<ACC, 2>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
-    else if (rem == 1) gemm_strip<ACC, 1>(C, ldc, AT, lda, Bq, ldb, i0, j0, K, scale);
+    if (rem == 3) gemm_strip<ACC, 3>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
+    else if (rem == 2) gemm_strip<ACC, 2>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
+    else if (rem == 1) gemm_strip<ACC, 1>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
   }
 }
 
