@@ -184,6 +184,8 @@ struct Solver {
   int dj_zero, status, iters, iters_outer;
   long long nbw, nro, ntr;
   long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+  // per-lane constants (lane T as state element T and as control element T), loaded once
+  double cwx = 0.0, cwfx = 0.0, cxmax = __builtin_inf(), cxmin = -__builtin_inf(), cwu = 0.0, cumax = __builtin_inf(), cumin = -__builtin_inf();
 
   __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(p.np), mp(p.mp), nz(p.n + p.m),
@@ -200,6 +202,8 @@ struct Solver {
     x0i = P.x0 + b * n;
     Xri = P.Xref + b * P.Nt * n; Uri = P.Uref + b * (P.Nt - 1) * m;
     for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
+    if (T < n) { cwx = P.wd[T]; cwfx = P.wf[T]; cxmax = P.zmax[T]; cxmin = P.zmin[T]; }
+    if (T < m) { cwu = P.wd[n + T]; cumax = P.zmax[n + T]; cumin = P.zmin[n + T]; }
     __syncthreads();
   }
 
@@ -282,37 +286,74 @@ struct Solver {
     return v;
   }
 
-  // cost!(obj, z_k) + max_violation of knot k; zb holds [x; u] of the knot (synchronised)
-  __device__ __forceinline__ void eval_knot(int k, bool term, double xv, double uv, double& J, double& viol) const {
-    const bool bx = box_at(k);
-    if (T < n) {
-      const double lhi = bx ? Lbi[((size_t)k * 2 + 0) * nz + T] : 0.0, llo = bx ? Lbi[((size_t)k * 2 + 1) * nz + T] : 0.0;
-      J += lane_cost(term ? P.wf[T] : P.wd[T], xv, Xri[(size_t)(kref + k) * n + T], P.zmax[T], P.zmin[T], lhi, llo, mu, bx, viol);
-    }
-    if (!term && T < m) {
-      const int j = n + T;
-      const double lhi = bx ? Lbi[((size_t)k * 2 + 0) * nz + j] : 0.0, llo = bx ? Lbi[((size_t)k * 2 + 1) * nz + j] : 0.0;
-      J += lane_cost(P.wd[j], uv, Uri[(size_t)(kref + k) * m + T], P.zmax[j], P.zmin[j], lhi, llo, mu, bx, viol);
-    }
-    if (T < Pn) {
-      const int ct = P.ctype[(size_t)k * Pn + T];
-      if (ct != 0) {
-        const double v = row_value(k, T, term), lam = Lci[(size_t)k * Pn + T];
-        const bool eq = ct == 1;
-        const bool act = eq || (v >= 0.0) || (lam > 0.0);
-        J += lam * v + (act ? 0.5 * mu * v * v : 0.0);
-        viol = fmax(viol, eq ? fabs(v) : v);
-      }
-    }
-  }
-
   struct RollOut {
     double J, cmax;
     bool limit;
   };
 
+  // per-lane operands of one rollout knot, requested one knot ahead of their use
+  struct KnotLd {
+    double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, lam, bc;
+    double kp[16];  // K_k[T][0..15] for the control lane T (the rest of a wider K is read on demand)
+    int ct;
+  };
+
+  __device__ __forceinline__ KnotLd load_knot(int k, bool term, bool open, const double* Xs, const double* Us) const {
+    KnotLd d;
+    const bool bx = box_at(k);
+    d.xs = d.us = d.dgv = d.xr = d.ur = d.lxh = d.lxl = d.luh = d.lul = d.lam = d.bc = 0.0;
+    d.ct = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) d.kp[u] = 0.0;
+    if (T < n) {
+      if (!open) d.xs = Xs[(size_t)k * n + T];
+      d.xr = Xri[(size_t)(kref + k) * n + T];
+      if (bx) {
+        d.lxh = Lbi[((size_t)k * 2 + 0) * nz + T];
+        d.lxl = Lbi[((size_t)k * 2 + 1) * nz + T];
+      }
+    }
+    if (!term && T < m) {
+      d.us = Us[(size_t)k * m + T];
+      d.ur = Uri[(size_t)(kref + k) * m + T];
+      if (bx) {
+        d.luh = Lbi[((size_t)k * 2 + 0) * nz + n + T];
+        d.lul = Lbi[((size_t)k * 2 + 1) * nz + n + T];
+      }
+      if (!open) {
+        d.dgv = dgi[(size_t)k * m + T];
+        const double* Kk = Kgi + (size_t)k * n * m + T;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) d.kp[u] = Kk[(size_t)(u < n ? u : n - 1) * m];
+      }
+    }
+    if (T < Pn) {
+      d.ct = P.ctype[(size_t)k * Pn + T];
+      d.lam = Lci[(size_t)k * Pn + T];
+      d.bc = P.bcon[(size_t)k * Pn + T];
+    }
+    return d;
+  }
+
+  // cost!(obj, z_k) + max_violation of knot k; zb holds [x; u] of the knot (synchronised)
+  __device__ __forceinline__ void eval_knot(int k, bool term, double xv, double uv, const KnotLd& d, double& J, double& viol) const {
+    const bool bx = box_at(k);
+    if (T < n) J += lane_cost(term ? cwfx : cwx, xv, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, bx, viol);
+    if (!term && T < m) J += lane_cost(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, bx, viol);
+    if (T < Pn && d.ct != 0) {
+      const double* At = P.AconT + (size_t)k * nz * Pn + T;
+      double v = dot_strided(At, Pn, zb, n, d.bc);
+      if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
+      const bool eq = d.ct == 1;
+      const bool act = eq || (v >= 0.0) || (d.lam > 0.0);
+      J += d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
+      viol = fmax(viol, eq ? fabs(v) : v);
+    }
+  }
+
   // rollout!(solver[, alpha]): open loop in place on plane cur, or closed loop from plane cur into
-  // plane cur^1 (oracle rollout_open / rollout_alpha), fused with cost! and max_violation
+  // plane cur^1 (oracle rollout_open / rollout_alpha), fused with cost! and max_violation.  The
+  // per-lane operands of knot k+1 are requested before knot k is processed.
   __device__ __forceinline__ RollOut rollout(bool open, double alpha) {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
@@ -321,21 +362,26 @@ struct Solver {
     double J = 0.0, viol = 0.0;
     bool lim = false;
     double xb = T < n ? x0i[T] : 0.0;
+    KnotLd d = load_knot(0, false, open, Xs, Us);
     for (int k = 0; k < N - 1; ++k) {
       WSTAMP(const long long s0 = wstamp();)
+      const bool last = k == N - 2;
+      const KnotLd dn = load_knot(k + 1, last, open, Xs, Us);   // knot N-1 is the terminal knot
       if (T < n) {
         zb[T] = xb;
-        if (!open) dxv[T] = xb - Xs[(size_t)k * n + T];
+        if (!open) dxv[T] = xb - d.xs;
         Xd[(size_t)k * n + T] = xb;
       }
       wsync();
       WSTAMP(const long long s1 = wstamp(); t_a += s1 - s0;)
       double uv = 0.0;
       if (T < m) {
-        double acc = Us[(size_t)k * m + T];
+        double acc = d.us;
         if (!open) {
-          acc += alpha * dgi[(size_t)k * m + T];
-          acc = dot_strided(Kgi + (size_t)k * n * m + T, m, dxv, n, acc);
+          acc += alpha * d.dgv;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += d.kp[u] * dxv[u];   // dxv is zero beyond n
+          if (n > 16) acc = dot_strided(Kgi + (size_t)k * n * m + (size_t)16 * m + T, m, dxv + 16, n - 16, acc);
           Ud[(size_t)k * m + T] = acc;
         }
         uv = acc;
@@ -343,7 +389,7 @@ struct Solver {
       }
       wsync();
       WSTAMP(const long long s2 = wstamp(); t_b += s2 - s1;)
-      eval_knot(k, false, xb, uv, J, viol);
+      eval_knot(k, false, xb, uv, d, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
       WSTAMP(const long long s3 = wstamp(); t_c += s3 - s2;)
       double xn = 0.0;
@@ -351,13 +397,14 @@ struct Solver {
       wsync();
       WSTAMP(t_d += wstamp() - s3;)
       xb = xn;
+      d = dn;
     }
     if (T < n) {
       zb[T] = xb;
       Xd[(size_t)(N - 1) * n + T] = xb;
     }
     wsync();
-    eval_knot(N - 1, true, xb, 0.0, J, viol);
+    eval_knot(N - 1, true, xb, 0.0, d, J, viol);
     lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value));
     __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
@@ -404,9 +451,9 @@ struct Solver {
     if (T < n) {
       const double x = Xs[(size_t)k * n + T];
       zb[T] = x;
-      const double w = term ? P.wf[T] : P.wd[T];
+      const double w = term ? cwfx : cwx;
       double q = w * (x - Xri[(size_t)(kref + k) * n + T]), h = w;
-      if (bx) box_expand(mu, x, P.zmax[T], P.zmin[T], Lbi[((size_t)k * 2) * nz + T], Lbi[((size_t)k * 2 + 1) * nz + T], q, h);
+      if (bx) box_expand(mu, x, cxmax, cxmin, Lbi[((size_t)k * 2) * nz + T], Lbi[((size_t)k * 2 + 1) * nz + T], q, h);
       qz[T] = q;
       hz[T] = h;
     }
@@ -415,10 +462,10 @@ struct Solver {
       if (!term) {
         const int j = n + T;
         u = Us[(size_t)k * m + T];
-        const double w = P.wd[j];
+        const double w = cwu;
         q = w * (u - Uri[(size_t)(kref + k) * m + T]);
         h = w;
-        if (bx) box_expand(mu, u, P.zmax[j], P.zmin[j], Lbi[((size_t)k * 2) * nz + j], Lbi[((size_t)k * 2 + 1) * nz + j], q, h);
+        if (bx) box_expand(mu, u, cumax, cumin, Lbi[((size_t)k * 2) * nz + j], Lbi[((size_t)k * 2 + 1) * nz + j], q, h);
       }
       zb[np + T] = u;
       qz[np + T] = q;
@@ -692,13 +739,14 @@ struct Solver {
           if (!on) continue;
           const int j = pass == 0 ? T : n + T;
           const double z = pass == 0 ? xv : uv;
-          if (P.zmax[j] < 1e300) {
+          const double zmx = pass == 0 ? cxmax : cumax, zmn = pass == 0 ? cxmin : cumin;
+          if (zmx < 1e300) {
             double* l = Lbi + ((size_t)k * 2) * nz + j;
-            *l = fmin(fmax(*l + mu * (z - P.zmax[j]), 0.0), dmax);
+            *l = fmin(fmax(*l + mu * (z - zmx), 0.0), dmax);
           }
-          if (P.zmin[j] > -1e300) {
+          if (zmn > -1e300) {
             double* l = Lbi + ((size_t)k * 2 + 1) * nz + j;
-            *l = fmin(fmax(*l + mu * (P.zmin[j] - z), 0.0), dmax);
+            *l = fmin(fmax(*l + mu * (zmn - z), 0.0), dmax);
           }
         }
       }
