@@ -36,8 +36,9 @@ struct Params {
   int box_k0, box_k1;
   const double* AconT;  // [N][n+m][Pn]: row r of knot k's table is column r
   const double* bcon;   // [N][Pn]
-  const int* ctype;     // [N][Pn]: 0 none, 1 equality, 2 inequality
+  const int* ctype;     // [N][Pn]: 0 none, 1 equality, 2 inequality, 3 row of a second-order cone
   const int *rowk0, *rowk1;  // [Pn] knot range of the constraint block that owns row r
+  const int *rowc0, *rowcp;  // [Pn] second-order cones: first row and dimension (2..4) of the cone that owns row r, 0 if none
   double* x0;           // [B][n]
   const double *Xref, *Uref;  // [B][Nt][n], [B][Nt-1][m]
   double *X, *U;        // [B][2][N][n], [B][2][N-1][m]
@@ -50,6 +51,7 @@ struct Params {
   const double *noise, *noise_w;
   const int* noise_grp;
   int noise_mode, mpc_shift;
+  int ncone;  // number of second-order cones among the generic rows
   int kref;
   altro_opts o;
 };
@@ -78,7 +80,7 @@ __host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
   L.Huu = o; o += mp * L.ldu;
   L.Ac = o; o += Pp * L.ldg;
   L.DA = o; o += Pp * L.ldg;
-  L.vec = o; o += 6 * nzp + 2 * np + 2 * (Pp + 4);
+  L.vec = o; o += 6 * nzp + 2 * np + 8 * (Pp + 4);
   L.total = o;
   return L;
 }
@@ -176,7 +178,8 @@ struct Solver {
   const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
   const Lds ly;
   double *G, *S, *W, *Hux, *Kl, *Huu, *Ac, *DA;
-  double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr;
+  double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr, *cvv, *cll, *Hc;
+  int myc0 = 0, mycp = 0;
   double *Xi, *Ui, *Lbi, *Lci, *Kgi, *dgi, *x0i;
   const double *Xri, *Uri;
   int cur, kref;
@@ -194,7 +197,10 @@ struct Solver {
     Ac = lds + ly.Ac; DA = lds + ly.DA;
     double* v = lds + ly.vec;
     zb = v; v += nzp; qz = v; v += nzp; hz = v; v += nzp; qv = v; v += nzp; v += 2 * nzp;
-    dxv = v; v += np; sv = v; v += np; gr = v; v += Pp + 4; Dr = v;
+    dxv = v; v += np; sv = v; v += np; gr = v; v += Pp + 4; Dr = v; v += Pp + 4; cvv = v; v += Pp + 4; cll = v; v += Pp + 4;
+    Hc = v;  // [Pp + 4][4] Hessian rows of the cone blocks
+    myc0 = (T < Pn) ? P.rowc0[T] : 0;
+    mycp = (T < Pn) ? P.rowcp[T] : 0;
     const size_t b = inst;
     Xi = P.X + b * 2 * N * n; Ui = P.U + b * 2 * (N - 1) * m;
     Lbi = P.Lb + b * N * 2 * nz; Lci = P.Lc + b * N * (Pn > 0 ? Pn : 1);
@@ -291,6 +297,140 @@ struct Solver {
     bool limit;
   };
 
+  // ---- second-order cone rows (oracle soc_project / con_cost / cost_expansion) -------------
+  // value v and dual lam of the whole cone are exchanged through LDS (cvv, cll); every lane of the
+  // cone evaluates the same small dense block (dimension <= 4) and keeps its own row.
+  struct Cone {
+    double cost;      // (1/2mu)(||Pi(lam - mu v)||^2 - ||lam||^2), counted once per cone (on its first row)
+    double viol;      // |Pi(v) - v| of this row
+    double lam_new;   // Pi(lam - mu v) of this row
+    double g;         // d phi / d v of this row
+    double h[4];      // this row of the Hessian block  mu (JPi'JPi [+ curvature])
+  };
+
+  static __device__ __forceinline__ void soc_proj4(const double (&x)[4], int p, double (&out)[4], int& br, double& nv, double& t) {
+    const int q = p - 1;
+    double s2 = 0.0;
+    t = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s2 += u < q ? x[u] * x[u] : 0.0;
+      t = u == q ? x[u] : t;
+    }
+    nv = sqrt(s2);
+    br = (nv <= t) ? 0 : ((nv <= -t) ? 1 : 2);
+    const double cc = 0.5 * (1.0 + t / nv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double b2 = u < q ? cc * x[u] : (u == q ? cc * nv : 0.0);
+      out[u] = br == 0 ? (u < p ? x[u] : 0.0) : (br == 1 ? 0.0 : b2);
+    }
+  }
+
+  template <bool HESS>
+  __device__ __forceinline__ Cone cone_eval(int r0, int p, int pos) const {
+    Cone c;
+    double v[4], lam[4], lb[4], lp[4], pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = u < p;
+      v[u] = in ? cvv[r0 + u] : 0.0;
+      lam[u] = in ? cll[r0 + u] : 0.0;
+      lb[u] = lam[u] - mu * v[u];
+    }
+    int br, brv;
+    double nv, t, nvv, tv;
+    soc_proj4(lb, p, lp, br, nv, t);
+    soc_proj4(v, p, pv, brv, nvv, tv);
+    double a2 = 0.0, l2 = 0.0;
+    c.viol = 0.0;
+    c.lam_new = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a2 += lp[u] * lp[u];
+      l2 += lam[u] * lam[u];
+      c.viol = u == pos ? fabs(pv[u] - v[u]) : c.viol;
+      c.lam_new = u == pos ? lp[u] : c.lam_new;
+    }
+    c.cost = pos == 0 ? (a2 - l2) / (2.0 * mu) : 0.0;
+    c.g = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c.h[u] = 0.0;
+    if constexpr (HESS) {
+      const int q = p - 1;
+      // Jacobian of the projection (symmetric)
+      double Jp[4][4];
+      const double cc = 0.5 * (1.0 + t / nv), i3 = 1.0 / (nv * nv * nv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double e = 0.0;
+          if (br == 0) e = (i == j && i < p) ? 1.0 : 0.0;
+          else if (br == 2) {
+            if (i < q && j < q) e = (i == j ? cc : 0.0) - 0.5 * t * lb[i] * lb[j] * i3;
+            else if (i < q && j == q) e = 0.5 * lb[i] / nv;
+            else if (i == q && j < q) e = 0.5 * lb[j] / nv;
+            else if (i == q && j == q) e = 0.5;
+          }
+          Jp[i][j] = e;
+        }
+      double g[4], H[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc += Jp[i][r] * lp[i];
+        g[r] = -acc;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc += Jp[r][i] * Jp[r][j];
+          H[i][j] = mu * acc;
+        }
+      if (P.o.soc_second_order != 0 && br == 2) {  // curvature of the projection contracted with y = Pi(lb)
+        double yv = 0.0, yt = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          yv += u < q ? lp[u] * lb[u] : 0.0;
+          yt = u == q ? lp[u] : yt;
+        }
+        const double i5 = i3 / (nv * nv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < q && j < q) {
+              const double dcc = -0.5 * t * lb[j] * i3;
+              const double term = dcc * lp[i] - 0.5 * t * ((i == j ? yv : 0.0) + lb[i] * lp[j]) * i3 + 1.5 * t * lb[i] * yv * lb[j] * i5 +
+                                  yt * ((i == j ? 1.0 : 0.0) / (2.0 * nv) - lb[i] * lb[j] * 0.5 * i3);
+              H[i][j] += mu * term;
+            }
+          if (i < q) {
+            const double dt = mu * (lp[i] / (2.0 * nv) - lb[i] * yv * 0.5 * i3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              H[i][j] += (j == q) ? dt : 0.0;
+              H[j][i] += (j == q) ? dt : 0.0;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c.g = r == pos ? g[r] : c.g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c.h[u] = r == pos ? H[r][u] : c.h[u];
+      }
+    }
+    return c;
+  }
+
+
   // per-lane operands of one rollout knot, requested one knot ahead of their use
   struct KnotLd {
     double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, lam, bc;
@@ -340,14 +480,30 @@ struct Solver {
     const bool bx = box_at(k);
     if (T < n) J += lane_cost(term ? cwfx : cwx, xv, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, bx, viol);
     if (!term && T < m) J += lane_cost(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, bx, viol);
+    double v = 0.0;
     if (T < Pn && d.ct != 0) {
       const double* At = P.AconT + (size_t)k * nz * Pn + T;
-      double v = dot_strided(At, Pn, zb, n, d.bc);
+      v = dot_strided(At, Pn, zb, n, d.bc);
       if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
-      const bool eq = d.ct == 1;
-      const bool act = eq || (v >= 0.0) || (d.lam > 0.0);
-      J += d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
-      viol = fmax(viol, eq ? fabs(v) : v);
+      if (d.ct != 3) {
+        const bool eq = d.ct == 1;
+        const bool act = eq || (v >= 0.0) || (d.lam > 0.0);
+        J += d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
+        viol = fmax(viol, eq ? fabs(v) : v);
+      }
+    }
+    if (P.ncone > 0) {
+      if (T < Pn) {
+        cvv[T] = v;
+        cll[T] = d.lam;
+      }
+      wsync();
+      if (T < Pn && d.ct == 3) {
+        const Cone c = cone_eval<false>(myc0, mycp, T - myc0);
+        J += c.cost;
+        viol = fmax(viol, c.viol);
+      }
+      wsync();
     }
   }
 
@@ -473,30 +629,66 @@ struct Solver {
     }
     wsync();
     if (Pn > 0) {
+      double v = 0.0, lam = 0.0;
+      int ct = 0;
       if (T < Pp) {
         double g = 0.0, D = 0.0;
         if (T < Pn) {
-          const int ct = P.ctype[(size_t)k * Pn + T];
+          ct = P.ctype[(size_t)k * Pn + T];
           if (ct != 0) {
-            const double v = row_value(k, T, term), lam = Lci[(size_t)k * Pn + T];
-            const bool act = (ct == 1) || (v >= 0.0) || (lam > 0.0);
-            g = lam + (act ? mu * v : 0.0);
-            D = act ? mu : 0.0;
+            v = row_value(k, T, term);
+            lam = Lci[(size_t)k * Pn + T];
+            if (ct != 3) {
+              const bool act = (ct == 1) || (v >= 0.0) || (lam > 0.0);
+              g = lam + (act ? mu * v : 0.0);
+              D = act ? mu : 0.0;
+            }
           }
         }
         gr[T] = g;
         Dr[T] = D;
+        if (P.ncone > 0) {
+          cvv[T] = v;
+          cll[T] = lam;
+        }
       }
       wsync();
+      if (P.ncone > 0) {
+        if (T < Pn) {
+          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+          if (ct == 3) {
+            const Cone c = cone_eval<true>(myc0, mycp, T - myc0);
+            gr[T] = c.g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h4[u] = c.h[u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) Hc[T * 4 + u] = h4[u];
+        }
+        wsync();
+      }
       const double* At = P.AconT + (size_t)k * nz * Pn;
       for (int e = T; e < nz * Pn; e += 64) {
         const int j = e / Pn, r = e - j * Pn;
-        const double v = (term && j >= n) ? 0.0 : At[e];
+        const double a = (term && j >= n) ? 0.0 : At[e];
         const int c = j < n ? j : np + (j - n);
-        Ac[r * ly.ldg + c] = v;
-        DA[r * ly.ldg + c] = Dr[r] * v;
+        Ac[r * ly.ldg + c] = a;
+        DA[r * ly.ldg + c] = Dr[r] * a;
       }
       wsync();
+      if (P.ncone > 0) {  // cone rows: DA = H_block * A over the rows of the cone
+        for (int e = T; e < nz * Pn; e += 64) {
+          const int j = e / Pn, r = e - j * Pn;
+          const int cp = P.rowcp[r];
+          if (cp > 0) {
+            const int c0 = P.rowc0[r], c = j < n ? j : np + (j - n);
+            double acc = 0.0;
+            for (int q = 0; q < cp; ++q) acc += Hc[r * 4 + q] * Ac[(c0 + q) * ly.ldg + c];
+            DA[r * ly.ldg + c] = acc;
+          }
+        }
+        wsync();
+      }
       for (int c = T; c < nzp; c += 64) {
         double acc = 0.0;
         for (int r = 0; r < Pn; ++r) acc += Ac[r * ly.ldg + c] * gr[r];
@@ -750,13 +942,23 @@ struct Solver {
           }
         }
       }
+      int ct = 0;
+      double rv = 0.0;
       if (T < Pn) {
-        const int ct = P.ctype[(size_t)k * Pn + T];
+        ct = P.ctype[(size_t)k * Pn + T];
         if (ct != 0) {
           double* l = Lci + (size_t)k * Pn + T;
-          const double v = *l + mu * row_value(k, T, term);
-          *l = fmin(fmax(v, ct == 1 ? -dmax : 0.0), dmax);
+          rv = row_value(k, T, term);
+          if (P.ncone > 0) {
+            cvv[T] = rv;
+            cll[T] = *l;
+          }
+          if (ct != 3) *l = fmin(fmax(*l + mu * rv, ct == 1 ? -dmax : 0.0), dmax);
         }
+      }
+      if (P.ncone > 0) {
+        wsync();
+        if (ct == 3) Lci[(size_t)k * Pn + T] = cone_eval<false>(myc0, mycp, T - myc0).lam_new;
       }
       wsync();
     }

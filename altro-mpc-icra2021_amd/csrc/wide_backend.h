@@ -56,7 +56,7 @@ struct WideBackend {
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr;
-  int *cur = nullptr, *ctype = nullptr, *rowk0 = nullptr, *rowk1 = nullptr, *iters = nullptr, *iters_outer = nullptr,
+  int *cur = nullptr, *ctype = nullptr, *rowk0 = nullptr, *rowk1 = nullptr, *rowc0 = nullptr, *rowcp = nullptr, *iters = nullptr, *iters_outer = nullptr,
       *status = nullptr, *noise_grp = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr, *noise = nullptr,
          *noise_w = nullptr;
@@ -68,10 +68,11 @@ struct WideBackend {
   int box_k0 = 0, box_k1 = -1, box_id = -1;
   struct Block {
     int id, sense, k0, k1, p, per_knot, r0;
+    bool soc = false;
     std::vector<double> A, b;  // row-major p x nz blocks
   };
   std::vector<Block> blocks;
-  int Pn = 0, ncon = 0;
+  int Pn = 0, ncon = 0, ncone = 0;
   bool con_dirty = false, con_locked = false;
 
   int np() const { return pad16(d.n); }
@@ -117,7 +118,7 @@ struct WideBackend {
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
     DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B);
     DA_(noise_w, kMaxN); DA_(noise_grp, kMaxN);
-    DA_(Lc, 1); DA_(AconT, 1); DA_(bcon, 1); DA_(ctype, 1); DA_(rowk0, 1); DA_(rowk1, 1);
+    DA_(Lc, 1); DA_(AconT, 1); DA_(bcon, 1); DA_(ctype, 1); DA_(rowk0, 1); DA_(rowk1, 1); DA_(rowc0, 1); DA_(rowcp, 1);
 #undef DA_
     {
       std::vector<double> inf(z, INFINITY), ninf(z, -INFINITY), w(kMaxN, 0.01), m0(B, 1.0);
@@ -134,7 +135,7 @@ struct WideBackend {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, AconT, bcon, stage, cur, ctype,
-                    rowk0, rowk1, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
+                    rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
                     n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok};
     for (void* p : ptrs)
       if (p) hipFree(p);
@@ -192,13 +193,13 @@ struct WideBackend {
       if (con_id) *con_id = box_id;
       return ALTRO_OK;
     }
-    if (kind == ALTRO_CON_SOC)
-      WFAIL(ALTRO_ERR_UNSUPPORTED, "second-order cones are built for n + m <= 16 only (this problem runs on the wide kernel)");
-    if (kind != ALTRO_CON_LINEAR || !A_ || !b_ || p < 1) return ALTRO_ERR_INVALID_ARG;
-    if (sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
+    if ((kind != ALTRO_CON_LINEAR && kind != ALTRO_CON_SOC) || !A_ || !b_ || p < 1) return ALTRO_ERR_INVALID_ARG;
+    if (kind == ALTRO_CON_SOC && (p < 2 || p > 4)) WFAIL(ALTRO_ERR_UNSUPPORTED, "second-order cones of dimension 2..4 only");
+    if (kind == ALTRO_CON_LINEAR && sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
     if (Pn + p > kMaxP) WFAIL(ALTRO_ERR_UNSUPPORTED, "more than 64 linear constraint rows");
     Block bl;
     bl.id = ncon++;
+    bl.soc = kind == ALTRO_CON_SOC;
     bl.sense = sense; bl.k0 = k_first; bl.k1 = k_last; bl.p = p; bl.per_knot = per_knot ? 1 : 0; bl.r0 = Pn;
     const size_t nb = per_knot ? (size_t)(k_last - k_first + 1) : 1;
     bl.A.assign(A_, A_ + nb * p * nz());
@@ -232,29 +233,35 @@ struct WideBackend {
     WCHK(hipSetDevice(device));
     const size_t N = d.N, z = nz(), P = Pn;
     std::vector<double> At(N * z * P, 0.0), bc(N * P, 0.0);
-    std::vector<int> ct(N * P, 0), k0(P, 0), k1(P, -1);
+    std::vector<int> ct(N * P, 0), k0(P, 0), k1(P, -1), c0(P, 0), cp(P, 0);
+    ncone = 0;
+    for (const auto& bl : blocks) ncone += bl.soc ? 1 : 0;
     for (const auto& bl : blocks)
       for (int r = 0; r < bl.p; ++r) {
         const int row = bl.r0 + r;
         k0[row] = bl.k0;
         k1[row] = bl.k1;
+        c0[row] = bl.soc ? bl.r0 : 0;
+        cp[row] = bl.soc ? bl.p : 0;
         for (int k = bl.k0; k <= bl.k1; ++k) {
           const size_t blk = bl.per_knot ? (size_t)(k - bl.k0) : 0;
-          ct[k * P + row] = bl.sense == ALTRO_SENSE_EQ ? 1 : 2;
+          ct[k * P + row] = bl.soc ? 3 : (bl.sense == ALTRO_SENSE_EQ ? 1 : 2);
           bc[k * P + row] = bl.b[blk * bl.p + r];
           for (size_t j = 0; j < z; ++j) At[(k * z + j) * P + row] = bl.A[(blk * bl.p + r) * z + j];
         }
       }
     if (!con_locked) {
-      for (void* p : {(void*)AconT, (void*)bcon, (void*)ctype, (void*)rowk0, (void*)rowk1, (void*)Lc})
+      for (void* p : {(void*)AconT, (void*)bcon, (void*)ctype, (void*)rowk0, (void*)rowk1, (void*)rowc0, (void*)rowcp, (void*)Lc})
         if (p) WCHK(hipFree(p));
       AconT = bcon = Lc = nullptr;
-      ctype = rowk0 = rowk1 = nullptr;
+      ctype = rowk0 = rowk1 = rowc0 = rowcp = nullptr;
       WCHK(hipMalloc(&AconT, At.size() * sizeof(double)));
       WCHK(hipMalloc(&bcon, bc.size() * sizeof(double)));
       WCHK(hipMalloc(&ctype, ct.size() * sizeof(int)));
       WCHK(hipMalloc(&rowk0, P * sizeof(int)));
       WCHK(hipMalloc(&rowk1, P * sizeof(int)));
+      WCHK(hipMalloc(&rowc0, P * sizeof(int)));
+      WCHK(hipMalloc(&rowcp, P * sizeof(int)));
       WCHK(hipMalloc(&Lc, (size_t)d.batch * N * P * sizeof(double)));
       WCHK(hipMemset(Lc, 0, (size_t)d.batch * N * P * sizeof(double)));
     }
@@ -263,6 +270,8 @@ struct WideBackend {
     WCHK(hipMemcpy(ctype, ct.data(), ct.size() * sizeof(int), hipMemcpyHostToDevice));
     WCHK(hipMemcpy(rowk0, k0.data(), P * sizeof(int), hipMemcpyHostToDevice));
     WCHK(hipMemcpy(rowk1, k1.data(), P * sizeof(int), hipMemcpyHostToDevice));
+    WCHK(hipMemcpy(rowc0, c0.data(), P * sizeof(int), hipMemcpyHostToDevice));
+    WCHK(hipMemcpy(rowcp, cp.data(), P * sizeof(int), hipMemcpyHostToDevice));
     con_dirty = false;
     return ALTRO_OK;
   }
@@ -350,7 +359,7 @@ struct WideBackend {
     p.ltv = ltv; p.dyn_per_instance = dyn_per_instance;
     p.A = A; p.Bm = Bm; p.f = f; p.wd = wd; p.wf = wf; p.zmin = zmin; p.zmax = zmax;
     p.box_k0 = box_k0; p.box_k1 = box_k1;
-    p.AconT = AconT; p.bcon = bcon; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1;
+    p.AconT = AconT; p.bcon = bcon; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1; p.rowc0 = rowc0; p.rowcp = rowcp; p.ncone = ncone;
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;

@@ -397,10 +397,12 @@ class QuadrupedData:
         return A, Bm, d
 
 
-def gen_quadruped_problem(N=15, dt=0.03, vx=0.0):
+def gen_quadruped_problem(N=15, dt=0.03, vx=0.0, linearized_friction=True):
     """AltroParams (Structs/ALTROParams.jl:32-108) with MPC.yaml's weights: n = m = 12, LQR about
     x_des with u_ref = 0, per leg the linearised friction pyramid |f_x|, |f_y| <= mu f_z (4 rows,
-    LinearizedFrictionConstraint.jl:14-25) on knots 1..N-1, 0 <= f_z <= 133 on every control."""
+    LinearizedFrictionConstraint.jl:14-25) on knots 1..N-1, 0 <= f_z <= 133 on every control.
+    linearized_friction=False gives the cone variant instead (FrictionConstraint.jl:1-8: NormConstraint2
+    with A = diag(1,1,0), c = mu e_z, i.e. (f_x, f_y, 0, mu f_z) in the second-order cone)."""
     n = m = 12
     q = np.array([1.0, 1.0, 500.0, 5000.0, 5000.0, 1000.0, 500.0, 1000.0, 1000.0, 500.0, 500.0, 100.0])
     r = np.tile([1.0, 1.0, 0.001], 4)
@@ -416,6 +418,10 @@ def gen_quadruped_problem(N=15, dt=0.03, vx=0.0):
     for leg in range(4):
         A = np.zeros((4, n + m))
         ix, iy, iz = n + 3 * leg, n + 3 * leg + 1, n + 3 * leg + 2
+        if not linearized_friction:
+            A[0, ix], A[1, iy], A[3, iz] = 1.0, 1.0, mu
+            cons.append(ConstraintSpec(SOC, 0, 0, N - 2, A=A, b=np.zeros(4)))
+            continue
         A[0, ix], A[0, iz] = 1.0, -mu
         A[1, ix], A[1, iz] = -1.0, -mu
         A[2, iy], A[2, iz] = 1.0, -mu

@@ -133,10 +133,12 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qdiag, cons
  *   LINEAR: A [p][n+m] ROW-major, b [p]; value A z + b {= 0 | <= 0}
  *   SOC:    A, b as above; value v = A z + b with ||v[0..p-2]|| <= v[p-1]
  *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67)
- * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; at most
+ * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; cones of
+ * dimension 2..4; on the 16-lane kernels ((n,m) in (12,4) (12,3) (8,4) (6,6) (6,3)) at most
  * 16 LINEAR / SOC rows are active at any one knot (a cone of dimension 2..4 takes the first lanes
  * of an aligned group of 4, linear rows take any free lane; constraints with disjoint knot
- * ranges share lanes); constraints are added before the first solve. */
+ * ranges share lanes); every other (n <= 64, m <= 32) runs on the one-wave-per-instance kernel with
+ * up to 64 LINEAR / SOC rows in total; constraints are added before the first solve. */
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first,
                                    int32_t k_last, int32_t p, const double* A, const double* b,
                                    const double* zmin, const double* zmax, int32_t per_knot,

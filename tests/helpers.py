@@ -178,7 +178,8 @@ def quadruped_gpu_problem(altro, qp, x0, A, Bm, d):
             bc = altro.BoundConstraint(qp.n, qp.m, u_min=c.zmin[qp.n:], u_max=c.zmax[qp.n:])
             cons.add_constraint(bc, (c.k_first + 1, c.k_last + 1))
         else:
-            cons.add_constraint(altro.LinearConstraint(c.A, c.b, equality=(c.sense == P.EQ)), (c.k_first + 1, c.k_last + 1))
+            con = altro.NormConstraint(c.A, c.b) if c.kind == P.SOC else altro.LinearConstraint(c.A, c.b, equality=(c.sense == P.EQ))
+            cons.add_constraint(con, (c.k_first + 1, c.k_last + 1))
     return altro.Problem(model, obj, cons, x0=x0.copy(), N=qp.N, U0=np.tile(qp.u_hover, (B, qp.N - 1, 1)))
 
 

@@ -96,15 +96,16 @@ def test_mpc_loop_wide_kernel_sizes_match_oracle(oracle, n, m, N):
             check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
 
 
-@pytest.mark.parametrize("N", [15, 40])
-def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N):
+@pytest.mark.parametrize("N,lin", [(15, True), (40, True), (15, False)])
+def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N, lin):
     """Quadruped MPC (BASELINE configs[4]; Woofer/MPCControl/altro_solver.jl:40-88): n = m = 12,
     per-knot affine dynamics re-linearised before every solve with the trot's contact mask
     (update_dynamics_matrices!), friction pyramids + f_z box, then set_initial_state!, primal and
     dual shift_fill!, solve!.  Every instance starts at its own gait phase and state error.
-    N = 15 is the reference's horizon (MPC.yaml:21), N = 40 BASELINE's."""
+    N = 15 is the reference's horizon (MPC.yaml:21), N = 40 BASELINE's; lin = False swaps the
+    pyramids for the second-order friction cones of FrictionConstraint.jl."""
     B, S = 6, 5
-    qp = P.gen_quadruped_problem(N=N)
+    qp = P.gen_quadruped_problem(N=N, linearized_friction=lin)
     rng = np.random.default_rng(7)
     t0 = rng.uniform(0.0, 0.8, B)
     x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
@@ -712,10 +713,10 @@ def test_error_paths():
     with pytest.raises(altro.AltroError) as e:
         altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
     assert e.value.code == altro._lib.ERR_UNSUPPORTED
-    # second-order cones are only built into the 16-lane kernels
+    # cones of dimension 5 fit neither kernel
     pb = altro.problems.gen_random_linear_batch(2, n=12, m=6, N=9, steps=1)
     prob = altro.mpc.gen_tracking_problem(pb)
-    prob.constraints.add_constraint(altro.NormConstraint(np.ones((3, 18)), np.zeros(3)), (1, 8))
+    prob.constraints.add_constraint(altro.NormConstraint(np.ones((5, 18)), np.zeros(5)), (1, 8))
     with pytest.raises(altro.AltroError) as e:
         altro.ALTROSolver(prob)
     assert e.value.code == altro._lib.ERR_UNSUPPORTED
