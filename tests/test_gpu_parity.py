@@ -707,6 +707,20 @@ def test_update_constraint_data_is_seen_by_the_next_solve(oracle):
     check_against_oracle(st, altro.states(sv), altro.controls(sv), 1, o, so)
 
 
+def test_wide_kernel_passes_the_16_lane_kernels_conic_and_lq_tests(oracle, monkeypatch):
+    """ALTRO_FORCE_WIDE=1 makes altro_batch_create pick the one-wave-per-instance kernel for every
+    size: the rocket (goal + three cones, cold and warm), grasp (per-knot cones and equalities, the
+    reference's stored trajectory), update_constraint_data and flexible-satellite tests above must
+    pass unchanged on it, i.e. the two kernels agree with the oracle and with each other."""
+    monkeypatch.setenv("ALTRO_FORCE_WIDE", "1")
+    test_rocket_cold_solve_with_cones_matches_oracle(oracle)
+    test_rocket_mpc_steps_with_cones_match_oracle(oracle)
+    test_grasp_cold_solve_matches_oracle_and_reference_fixture(oracle)
+    test_update_constraint_data_is_seen_by_the_next_solve(oracle)
+    test_flexible_satellite_mpc_matches_oracle(oracle)
+    test_cold_solve_far_from_reference_matches_oracle(oracle)
+
+
 def test_error_paths():
     # n > 64 is outside both kernels
     pb = altro.problems.gen_random_linear_batch(2, n=70, m=2, N=9, steps=1)
