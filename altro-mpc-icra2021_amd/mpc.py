@@ -110,3 +110,38 @@ class TrackMPC:
     synchronize = BatchMPC.synchronize
     step = BatchMPC.step
     x0 = BatchMPC.x0
+
+
+def _add_specs(cons, specs, n, m):
+    from . import problems as P
+    for c in specs:
+        if c.kind == P.BOX:
+            cons.add_constraint(api.BoundConstraint(n, m, u_min=c.zmin[n:], u_max=c.zmax[n:]), (c.k_first + 1, c.k_last + 1))
+        else:
+            con = api.NormConstraint(c.A, c.b) if c.kind == P.SOC else api.LinearConstraint(c.A, c.b, equality=(c.sense == P.EQ))
+            cons.add_constraint(con, (c.k_first + 1, c.k_last + 1))
+
+
+def constrained_problem(data, x0, Xref=None, Uref=None, U0=None, constraints=None):
+    """Problem(model, objective, ...; constraints) for the rocket / grasp data of problems.py
+    (rocket_landing_problem.jl:66-186, grasp_problem.jl:1-107): x0 is (B, n); the reference
+    defaults to the goal state, the initial controls to the data's guess."""
+    B = x0.shape[0]
+    model = api.LinearModel(data.A, data.Bm, data.f, dt=data.dt)
+    Xr = np.tile(data.xf, (B, data.N, 1)) if Xref is None else Xref
+    Ur = np.zeros((B, data.N - 1, data.m)) if Uref is None else Uref
+    obj = api.TrackingObjective(data.Q, data.R, data.Qf, Xr, Ur)
+    cons = api.ConstraintList(data.n, data.m, data.N)
+    _add_specs(cons, data.constraints if constraints is None else constraints, data.n, data.m)
+    return api.Problem(model, obj, cons, x0=x0, N=data.N, U0=np.tile(data.U0, (B, 1, 1)) if U0 is None else U0)
+
+
+def quadruped_problem(qp, x0, A, Bm, d):
+    """AltroParams (Structs/ALTROParams.jl:32-108) for a batch: x0 (B, 12); A, Bm, d per instance
+    and per knot, (B, N-1, 12, 12) and (B, N-1, 12)."""
+    B = x0.shape[0]
+    model = api.LinearModel(A, Bm, d, dt=qp.dt, per_knot=True)
+    obj = api.TrackingObjective(qp.Q, qp.R, qp.Q, np.tile(qp.x_des, (B, qp.N, 1)), np.zeros((B, qp.N - 1, qp.m)))
+    cons = api.ConstraintList(qp.n, qp.m, qp.N)
+    _add_specs(cons, qp.constraints, qp.n, qp.m)
+    return api.Problem(model, obj, cons, x0=x0.copy(), N=qp.N, U0=np.tile(qp.u_hover, (B, qp.N - 1, 1)))
