@@ -698,6 +698,68 @@ struct Solver {
     }
   }
 
+  // value of v on lane `lane` (wave-uniform index), to every lane: two v_readlane_b32
+  static __device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+  }
+
+  // Quu_reg = L D L' and K = -Quu_reg^-1 [Qux | Qu] with the matrices in REGISTERS (m <= MP <= 16):
+  // lane b < m holds column b of Quu_reg, lane c holds column c of [Qux | Qu]; the scalars of L are
+  // handed round with v_readlane.  The LDS version below walks dependent read-modify-write chains
+  // (~128 cycles per element: 40 k cycles per knot at m = 12); this one is a few hundred VALU
+  // instructions.  Returns true if a pivot is not positive.
+  template <int MP>
+  __device__ __forceinline__ bool factor_solve_regs() {
+    const int ldh = ly.ldh, ldu = ly.ldu;
+    double cL[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) cL[i] = (T < m && i < m) ? Huu[i * ldu + T] : 0.0;
+    bool fail = false;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) {
+      if (j < m) {
+        const double dj = lane_bcast(cL[j], j);
+        fail = fail || !(dj > 0.0);
+        const double f = cL[j] * (1.0 / dj);  // lane b > j: A[j][b] / d_j = L[b][j]
+#pragma unroll
+        for (int i = j + 1; i < MP; ++i) {
+          const double aij = lane_bcast(cL[i], j);  // A[i][j] = L[i][j] d_j
+          cL[i] = (T > j) ? cL[i] - aij * f : ((T == j) ? cL[i] * (1.0 / dj) : cL[i]);
+        }
+      }
+    }
+    if (fail) return true;  // wave-uniform: every lane saw the same pivots
+    // lane j now holds d_j in cL[j] and L[i][j] in cL[i], i > j
+    for (int c0 = 0; c0 <= np; c0 += 64) {
+      const int c = c0 + T;
+      const bool mine = (c < n) || (c == np);
+      double q[MP];
+#pragma unroll
+      for (int a = 0; a < MP; ++a) q[a] = (mine && a < m) ? Kl[a * ldh + c] : 0.0;
+#pragma unroll
+      for (int k = 0; k < MP; ++k)          // forward: L y = b
+#pragma unroll
+        for (int i = k + 1; i < MP; ++i)
+          if (i < m) q[i] -= lane_bcast(cL[i], k) * q[k];
+#pragma unroll
+      for (int a = 0; a < MP; ++a)
+        if (a < m) q[a] /= lane_bcast(cL[a], a);
+#pragma unroll
+      for (int k = MP - 1; k >= 0; --k)     // backward: L' x = y
+#pragma unroll
+        for (int i = 0; i < k; ++i)
+          if (k < m) q[i] -= lane_bcast(cL[k], i) * q[k];
+      if (mine) {
+#pragma unroll
+        for (int a = 0; a < MP; ++a)
+          if (a < m) Kl[a * ldh + c] = -q[a];
+      }
+    }
+    return false;
+  }
+
   // backwardpass! (oracle backward_pass).  Returns true if a pivot of Quu + rho I was not positive.
   __device__ __forceinline__ bool backward(double& dV1, double& dV2) {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
@@ -741,33 +803,42 @@ struct Solver {
       for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];
       if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
       wsync();
-      // Quu_reg = L D L' in place (unit L below the diagonal, D on it)
-      for (int j = 0; j < m; ++j) {
-        const double dj = Huu[j * ldu + j];
-        if (!(dj > 0.0)) return true;  // wave-uniform
-        if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
-        wsync();
-        if (T > j && T < m) {
-          const double li = Huu[T * ldu + j];
-          for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
+      if (m <= 16) {
+        bool fail;
+        if (m <= 4) fail = factor_solve_regs<4>();
+        else if (m <= 8) fail = factor_solve_regs<8>();
+        else if (m <= 12) fail = factor_solve_regs<12>();
+        else fail = factor_solve_regs<16>();
+        if (fail) return true;
+      } else {
+        // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
+        for (int j = 0; j < m; ++j) {
+          const double dj = Huu[j * ldu + j];
+          if (!(dj > 0.0)) return true;  // wave-uniform
+          if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
+          wsync();
+          if (T > j && T < m) {
+            const double li = Huu[T * ldu + j];
+            for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
+          }
+          wsync();
         }
-        wsync();
-      }
-      // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
-      for (int c = T; c <= np; c += 64) {
-        if (c < n || c == np) {
-          for (int i = 0; i < m; ++i) {
-            double v = Kl[i * ldh + c];
-            for (int kk = 0; kk < i; ++kk) v -= Huu[i * ldu + kk] * Kl[kk * ldh + c];
-            Kl[i * ldh + c] = v;
+        // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
+        for (int c = T; c <= np; c += 64) {
+          if (c < n || c == np) {
+            for (int i = 0; i < m; ++i) {
+              double v = Kl[i * ldh + c];
+              for (int kk = 0; kk < i; ++kk) v -= Huu[i * ldu + kk] * Kl[kk * ldh + c];
+              Kl[i * ldh + c] = v;
+            }
+            for (int i = 0; i < m; ++i) Kl[i * ldh + c] /= Huu[i * ldu + i];
+            for (int i = m - 1; i >= 0; --i) {
+              double v = Kl[i * ldh + c];
+              for (int kk = i + 1; kk < m; ++kk) v -= Huu[kk * ldu + i] * Kl[kk * ldh + c];
+              Kl[i * ldh + c] = v;
+            }
+            for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
           }
-          for (int i = 0; i < m; ++i) Kl[i * ldh + c] /= Huu[i * ldu + i];
-          for (int i = m - 1; i >= 0; --i) {
-            double v = Kl[i * ldh + c];
-            for (int kk = i + 1; kk < m; ++kk) v -= Huu[kk * ldu + i] * Kl[kk * ldh + c];
-            Kl[i * ldh + c] = v;
-          }
-          for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
         }
       }
       wsync();
