@@ -520,7 +520,6 @@ struct Solver {
     double xb = T < n ? x0i[T] : 0.0;
     KnotLd d = load_knot(0, false, open, Xs, Us);
     for (int k = 0; k < N - 1; ++k) {
-      WSTAMP(const long long s0 = wstamp();)
       const bool last = k == N - 2;
       const KnotLd dn = load_knot(k + 1, last, open, Xs, Us);   // knot N-1 is the terminal knot
       if (T < n) {
@@ -529,7 +528,6 @@ struct Solver {
         Xd[(size_t)k * n + T] = xb;
       }
       wsync();
-      WSTAMP(const long long s1 = wstamp(); t_a += s1 - s0;)
       double uv = 0.0;
       if (T < m) {
         double acc = d.us;
@@ -544,14 +542,11 @@ struct Solver {
         zb[np + T] = acc;
       }
       wsync();
-      WSTAMP(const long long s2 = wstamp(); t_b += s2 - s1;)
       eval_knot(k, false, xb, uv, d, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
-      WSTAMP(const long long s3 = wstamp(); t_c += s3 - s2;)
       double xn = 0.0;
       if (T < n) xn = next_state(k);
       wsync();
-      WSTAMP(t_d += wstamp() - s3;)
       xb = xn;
       d = dn;
     }
@@ -713,20 +708,24 @@ struct Solver {
   template <int MP>
   __device__ __forceinline__ bool factor_solve_regs() {
     const int ldh = ly.ldh, ldu = ly.ldu;
-    double cL[MP];
+    double cL[MP], invd[MP];
 #pragma unroll
-    for (int i = 0; i < MP; ++i) cL[i] = (T < m && i < m) ? Huu[i * ldu + T] : 0.0;
+    for (int i = 0; i < MP; ++i) {
+      cL[i] = (T < m && i < m) ? Huu[i * ldu + T] : 0.0;
+      invd[i] = 0.0;
+    }
     bool fail = false;
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
       if (j < m) {
         const double dj = lane_bcast(cL[j], j);
         fail = fail || !(dj > 0.0);
-        const double f = cL[j] * (1.0 / dj);  // lane b > j: A[j][b] / d_j = L[b][j]
+        invd[j] = 1.0 / dj;
+        const double f = cL[j] * invd[j];  // lane b > j: A[j][b] / d_j = L[b][j]
 #pragma unroll
         for (int i = j + 1; i < MP; ++i) {
           const double aij = lane_bcast(cL[i], j);  // A[i][j] = L[i][j] d_j
-          cL[i] = (T > j) ? cL[i] - aij * f : ((T == j) ? cL[i] * (1.0 / dj) : cL[i]);
+          cL[i] = (T > j) ? cL[i] - aij * f : ((T == j) ? cL[i] * invd[j] : cL[i]);
         }
       }
     }
@@ -737,15 +736,14 @@ struct Solver {
       const bool mine = (c < n) || (c == np);
       double q[MP];
 #pragma unroll
-      for (int a = 0; a < MP; ++a) q[a] = (mine && a < m) ? Kl[a * ldh + c] : 0.0;
+      for (int a = 0; a < MP; ++a) q[a] = (mine && a < m) ? Hux[a * ldh + c] : 0.0;
 #pragma unroll
       for (int k = 0; k < MP; ++k)          // forward: L y = b
 #pragma unroll
         for (int i = k + 1; i < MP; ++i)
           if (i < m) q[i] -= lane_bcast(cL[i], k) * q[k];
 #pragma unroll
-      for (int a = 0; a < MP; ++a)
-        if (a < m) q[a] /= lane_bcast(cL[a], a);
+      for (int a = 0; a < MP; ++a) q[a] *= invd[a];  // 1/d_a (zero beyond m)
 #pragma unroll
       for (int k = MP - 1; k >= 0; --k)     // backward: L' x = y
 #pragma unroll
@@ -776,8 +774,10 @@ struct Solver {
     dV2 = 0.0;
     wsync();
     for (int k = N - 2; k >= 0; --k) {
+      WSTAMP(const long long b0 = wstamp();)
       if (P.ltv) load_dyn(k);
       expansion(k, false);  // ends with a barrier
+      WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
       // Q_z = l_z + [A B]' s
       for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
       WSTAMP(const long long tg = wstamp();)
@@ -800,7 +800,9 @@ struct Solver {
         gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
         wsync();
       }
-      for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];
+      WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
+      if (m > 16)
+        for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];  // the LDS solve works in place on a copy of [Qux | Qu]
       if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
       wsync();
       if (m <= 16) {
@@ -842,16 +844,20 @@ struct Solver {
         }
       }
       wsync();
+      WSTAMP(const long long b3 = wstamp(); t_c += b3 - b2;)
       // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
       {
-        double t1 = 0.0, dd = 0.0;
+        double p1 = 0.0, p2 = 0.0;
         if (T < m) {
           const double d = Kl[T * ldh + np];
-          t1 = d * Hux[T * ldh + np];
-          dd = d * d;
+          p1 = d * Hux[T * ldh + np];
+          p2 = d * d;
         }
-        t1 = wave_sum(t1);
-        dd = wave_sum(dd);
+        double t1 = 0.0, dd = 0.0;
+        for (int a = 0; a < m; ++a) {  // m terms in the oracle's order; v_readlane is far cheaper than a 6-step shuffle tree
+          t1 += lane_bcast(p1, a);
+          dd += lane_bcast(p2, a);
+        }
         dV1 += t1;
         dV2 += -0.5 * t1 - 0.5 * rho * dd;
       }
@@ -879,6 +885,7 @@ struct Solver {
       }
       if (T < m) dgi[(size_t)k * m + T] = Kl[T * ldh + np];
       wsync();
+      WSTAMP(t_d += wstamp() - b3;)
     }
     return false;
   }

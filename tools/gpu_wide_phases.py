@@ -17,4 +17,4 @@ ns, ni, nok = altro.solve_counters(mp.solver)
 print("n=%d m=%d N=%d B=%d: %.1f ms/step; per instance-solve (Mcycles): backward %.3f (gemm part %.3f) rollouts %.3f ; iterations/solve %.2f" % (
     n, m, N, B, 1e3 * dt / 4, tb.mean() / 4e6, tg.mean() / 4e6, tr.mean() / 4e6, ni.sum() / ns.sum()))
 st = altro.stats(mp.solver)
-print("   rollout segments (Mcycles per instance over 4 steps): x-write %.3f  u=Kdx %.3f  cost %.3f  next-state %.3f" % tuple(st.cost_trace[:, 12 + i].mean() / 1e6 for i in range(4)))
+print("   backward segments (Mcycles per instance over 4 steps): expansion %.3f  qv+gemms+rows %.3f  factor+solve %.3f  S update, gains %.3f" % tuple(st.cost_trace[:, 12 + i].mean() / 1e6 for i in range(4)))
