@@ -721,6 +721,20 @@ def test_wide_kernel_passes_the_16_lane_kernels_conic_and_lq_tests(oracle, monke
     test_cold_solve_far_from_reference_matches_oracle(oracle)
 
 
+def test_benchmark_script_functions_run():
+    """benchmarks.py restates the reference's four benchmark scripts as functions; small batches here."""
+    from altro_mpc_icra2021_amd import benchmarks as Bm
+    r = Bm.summarise(Bm.run_random_linear(batch=16, steps=5))
+    assert r["iterations_median"] == 2.0 and r["solve_succeeded_frac"] == 1.0
+    r = Bm.summarise(Bm.run_rocket(batch=8, N_mpc=21, steps=4, N_cold=61, dt=0.25))
+    assert r["solve_succeeded_frac"] >= 0.9
+    r = Bm.summarise(Bm.run_grasp(batch=4, N_mpc=11, steps=3, N_cold=41, tf=4.0))
+    assert r["solve_succeeded_frac"] == 1.0 and r["iterations_median"] <= 4.0      # the reference's grasp MPC median is 3
+    for lin in (True, False):
+        r = Bm.summarise(Bm.run_quadruped(batch=8, N=15, steps=3, linearized_friction=lin))
+        assert r["solve_succeeded_frac"] == 1.0
+
+
 def test_error_paths():
     # n > 64 is outside both kernels
     pb = altro.problems.gen_random_linear_batch(2, n=70, m=2, N=9, steps=1)
