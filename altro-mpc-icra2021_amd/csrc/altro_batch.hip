@@ -536,6 +536,28 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
   return ALTRO_OK;
 }
 
+// release everything the 16-lane backend owns on the device (the handle itself stays)
+static void free_dpp_backend(altro_handle* h) {
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void** ptrs[] = {(void**)&h->Gcol, (void**)&h->Grow, (void**)&h->fvec, (void**)&h->wd, (void**)&h->wf, (void**)&h->zmin, (void**)&h->zmax,
+                   (void**)&h->x0, (void**)&h->Zref, (void**)&h->Z, (void**)&h->Lb, (void**)&h->bslot, (void**)&h->Acon, (void**)&h->bcon,
+                   (void**)&h->cmeta, (void**)&h->Lc, (void**)&h->lanebuf, (void**)&h->noise_w, (void**)&h->noise_grp, (void**)&h->mu,
+                   (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
+                   (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
+                   (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
+                   (void**)&h->n_ok, (void**)&h->n_trials};
+  for (void** p : ptrs)
+    if (*p) { hipFree(*p); *p = nullptr; }
+  h->stage_bytes = 0;
+  for (hipEvent_t e : h->hist) hipEventDestroy(e);
+  h->hist.clear();
+  h->hist_used = 0;
+  if (h->ev0) { hipEventDestroy(h->ev0); h->ev0 = nullptr; }
+  if (h->ev1) { hipEventDestroy(h->ev1); h->ev1 = nullptr; }
+  if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
+}
+
 int32_t altro_batch_destroy(altro_handle* h) {
   if (!h) return ALTRO_OK;
   if (h->wide) {
@@ -544,17 +566,7 @@ int32_t altro_batch_destroy(altro_handle* h) {
     delete h;
     return ALTRO_OK;
   }
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->Gcol, h->Grow, h->fvec, h->wd, h->wf, h->zmin, h->zmax, h->x0, h->Zref, h->Z, h->Lb, h->bslot, h->Acon, h->bcon, h->cmeta, h->Lc, h->lanebuf, h->noise_w, h->noise_grp,
-                  h->mu, h->KD, h->noise, h->cur, h->iters, h->iters_outer, h->status, h->cost, h->cmax, h->Jtrace,
-                  h->ctrace, h->atrace, h->stage, h->n_backward, h->n_rollout, h->wave_cycles, h->n_solves, h->n_iters, h->n_ok, h->n_trials};
-  for (void* p : ptrs)
-    if (p) hipFree(p);
-  for (hipEvent_t e : h->hist) hipEventDestroy(e);
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
-  if (h->stream) hipStreamDestroy(h->stream);
+  free_dpp_backend(h);
   delete h;
   return ALTRO_OK;
 }
@@ -563,7 +575,28 @@ int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double*
                                  int32_t per_knot, int32_t per_instance) {
   WIDE_FWD(h, set_dynamics(A, B, f, per_knot, per_instance));
   if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
-  if (per_knot) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot (LTV) dynamics are not built yet");
+  if (per_knot) {
+    // Per-knot (LTV) dynamics exist on the one-wave-per-instance kernel only.  A handle on which nothing
+    // but create has happened moves there; the Julia model is fixed when ALTROSolver(prob, opts) is built
+    // (ALTROParams.jl:61,96), so set_dynamics is the first call of every harness.
+    if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
+      FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
+                                     "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
+    altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
+    if (!wb) FAIL(h, ALTRO_ERR_INVALID_ARG, "out of host memory");
+    free_dpp_backend(h);
+    const int rc = wb->create(&h->d, &h->o, h->device);
+    if (rc) {
+      h->err = wb->err;
+      wb->destroy();
+      delete wb;
+      return rc;
+    }
+    h->wide = wb;
+    const int rc2 = wb->set_dynamics(A, B, f, per_knot, per_instance);
+    if (rc2) h->err = wb->err;
+    return rc2;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = h->d.n, m = h->d.m;
   const size_t nb = per_instance ? h->d.batch : 1;

@@ -116,7 +116,8 @@ const char* altro_last_error(const altro_handle* h);
 /* RD.LinearModel(A, B[, d]; dt): random_linear_problem.jl:8; LTV/affine: ALTROParams.jl:61,
  * linearized_dynamics.jl:69-96.   x+ = A x + B u + f.
  *   per_instance != 0: arrays hold `batch` blocks, else one block shared by all instances
- *   per_knot     != 0: each block holds N-1 knot blocks (LTV)
+ *   per_knot     != 0: each block holds N-1 knot blocks (LTV); for an (n, m) of the 16-lane kernel set this
+ *                      must be the first call after create (the handle then moves to the wide kernel)
  * f may be NULL (zero). */
 int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
                                  int32_t per_knot, int32_t per_instance);

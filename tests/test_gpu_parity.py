@@ -721,6 +721,31 @@ def test_wide_kernel_passes_the_16_lane_kernels_conic_and_lq_tests(oracle, monke
     test_cold_solve_far_from_reference_matches_oracle(oracle)
 
 
+def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
+    """RD.LinearModel with `times` (per-knot A_k, B_k, d_k; ALTROParams.jl:61) at (n, m) = (12, 4): the
+    16-lane kernels hold time-invariant dynamics only, so altro_batch_set_dynamics moves the fresh
+    handle to the one-wave-per-instance kernel."""
+    B, n, m, N = 5, 12, 4, 25
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=1, seed=33)
+    rng = np.random.default_rng(33)
+    scale = 1.0 + 0.1 * rng.standard_normal((N - 1, 1, 1))
+    A = pb.A[:, None] * scale[None]                                   # (B, N-1, n, n): per instance and per knot
+    Bm = pb.Bm[:, None] * (1.0 + 0.1 * rng.standard_normal((N - 1, 1, 1)))[None]
+    d = 0.05 * rng.standard_normal((B, N - 1, n))
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.model = altro.LinearModel(A, Bm, d, dt=pb.dt, per_knot=True)
+    prob.x0 = prob.x0 + rng.standard_normal(prob.x0.shape)
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**REF_OPTS))
+    assert altro.wave_cycles(sv).size == 0
+    altro.solve(sv)
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    for b in range(B):
+        o = make_oracle(oracle, pb, b)
+        o.set_dynamics(A[b], Bm[b], d[b])
+        o.set_initial_state(prob.x0[b])
+        check_against_oracle(st, X, U, b, o, o.solve())
+
+
 def test_benchmark_script_functions_run():
     """benchmarks.py restates the reference's four benchmark scripts as functions; small batches here."""
     from altro_mpc_icra2021_amd import benchmarks as Bm
