@@ -5,7 +5,7 @@
      simple_rocket.jl:59-82), with the rocket's plant-noise model
 A few instances are checked against the CPU oracle."""
 import sys, os, time, json
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (R, os.path.join(R, "oracle"), os.path.join(R, "tests")):
     sys.path.insert(0, p)
 import numpy as np

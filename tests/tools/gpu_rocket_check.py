@@ -1,6 +1,6 @@
 """Ad-hoc GPU check of the conic path: rocket landing cold solve vs the CPU oracle."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (R, os.path.join(R, "oracle"), os.path.join(R, "tests")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,7 +1,7 @@
 """Localise a GPU/oracle difference: run MPC step 0 of the rocket problem with a cap of K total
 iLQR iterations on both sides and print where the trajectories start to differ."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (R, os.path.join(R, "oracle"), os.path.join(R, "tests")):
     sys.path.insert(0, p)
 import numpy as np

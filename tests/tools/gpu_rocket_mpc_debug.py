@@ -1,6 +1,6 @@
 """Find the first MPC step where the GPU conic path and the oracle diverge (rocket, N_mpc=100)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (R, os.path.join(R, "oracle"), os.path.join(R, "tests")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,6 +1,6 @@
 """Per (step, instance) comparison table of the horizon-N rocket MPC: GPU fused loop vs oracle."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (R, os.path.join(R, "oracle"), os.path.join(R, "tests")):
     sys.path.insert(0, p)
 import numpy as np
