@@ -1416,7 +1416,7 @@ struct Solver {
 // each in the reference's order (random_linear_problem.jl:125-139,161): plant step + noise -> x0;
 // reference window <- step+1; shift_fill primal and dual; solve.
 template <int NX, int NU, bool CONES>
-__global__ void __launch_bounds__(64, ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
+__global__ void __launch_bounds__(64, CONES ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
   const long long t0 = __builtin_amdgcn_s_memtime();
