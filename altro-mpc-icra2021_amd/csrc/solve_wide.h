@@ -52,6 +52,8 @@ struct Params {
   const int* noise_grp;
   int noise_mode, mpc_shift;
   int ncone;  // number of second-order cones among the generic rows
+  int con_static;  // nonzero: no constraint block has per-knot data, the row table is the same at every knot of a row's
+                   // range and stays in LDS (bits: 1 rollouts, 2 row values of expansion / dual update, 4 expansion tables)
   int kref;
   altro_opts o;
 };
@@ -286,10 +288,21 @@ struct Solver {
   // value of generic row r at knot k from zb (padded layout: x at [0,n), u at [np, np+m))
   __device__ __forceinline__ double row_value(int k, int r, bool term) const {
     double v = P.bcon[(size_t)k * Pn + r];
+    if ((P.con_static & 2) && !term) return dot_lds(Ac + r * ly.ldg, 1, zb, 1, nzp, v);  // table resident in LDS
     const double* At = P.AconT + (size_t)k * nz * Pn + r;
     v = dot_strided(At, Pn, zb, n, v);
     if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
     return v;
+  }
+
+  // time-invariant constraint data: the table lives in Ac for the whole launch (row r taken from the
+  // first knot of its range); rows that are inactive at a knot get zero weights, so they do no harm
+  __device__ __forceinline__ void build_static_Ac() {
+    for (int e = T; e < nz * Pn; e += 64) {
+      const int j = e / Pn, r = e - j * Pn;
+      const int c = j < n ? j : np + (j - n);
+      Ac[r * ly.ldg + c] = P.AconT[((size_t)P.rowk0[r] * nz + j) * Pn + r];
+    }
   }
 
   struct RollOut {
@@ -482,9 +495,13 @@ struct Solver {
     if (!term && T < m) J += lane_cost(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, bx, viol);
     double v = 0.0;
     if (T < Pn && d.ct != 0) {
-      const double* At = P.AconT + (size_t)k * nz * Pn + T;
-      v = dot_strided(At, Pn, zb, n, d.bc);
-      if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
+      if ((P.con_static & 1) && !term) {
+        v = dot_lds(Ac + T * ly.ldg, 1, zb, 1, nzp, d.bc);
+      } else {
+        const double* At = P.AconT + (size_t)k * nz * Pn + T;
+        v = dot_strided(At, Pn, zb, n, d.bc);
+        if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
+      }
       if (d.ct != 3) {
         const bool eq = d.ct == 1;
         const bool act = eq || (v >= 0.0) || (d.lam > 0.0);
@@ -663,11 +680,12 @@ struct Solver {
         wsync();
       }
       const double* At = P.AconT + (size_t)k * nz * Pn;
+      const bool resident = (P.con_static & 4) && !term;
       for (int e = T; e < nz * Pn; e += 64) {
         const int j = e / Pn, r = e - j * Pn;
-        const double a = (term && j >= n) ? 0.0 : At[e];
         const int c = j < n ? j : np + (j - n);
-        Ac[r * ly.ldg + c] = a;
+        const double a = resident ? Ac[r * ly.ldg + c] : ((term && j >= n) ? 0.0 : At[e]);
+        if (!resident) Ac[r * ly.ldg + c] = a;
         DA[r * ly.ldg + c] = Dr[r] * a;
       }
       wsync();
@@ -770,6 +788,10 @@ struct Solver {
     }
     wsync();
     if (Pn > 0) gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
+    if (Pn > 0 && P.con_static) {
+      wsync();
+      build_static_Ac();  // the terminal knot zeroed the control columns
+    }
     dV1 = 0.0;
     dV2 = 0.0;
     wsync();
@@ -1132,10 +1154,9 @@ struct Solver {
     kref = P.kref;
     nbw = nro = ntr = 0;
     long long nsolve = 0, nit = 0, nok = 0;
-    if (!P.ltv) {
-      load_dyn(0);
-      wsync();
-    }
+    if (!P.ltv) load_dyn(0);                                   // time-invariant dynamics stay resident in LDS
+    if (Pn > 0 && P.con_static) build_static_Ac();           // and so does a time-invariant constraint table
+    wsync();
     const int steps = mpc ? nsteps : 1;
     for (int s = 0; s < steps; ++s) {
       if (mpc) {

@@ -360,6 +360,9 @@ struct WideBackend {
     p.A = A; p.Bm = Bm; p.f = f; p.wd = wd; p.wf = wf; p.zmin = zmin; p.zmax = zmax;
     p.box_k0 = box_k0; p.box_k1 = box_k1;
     p.AconT = AconT; p.bcon = bcon; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1; p.rowc0 = rowc0; p.rowcp = rowcp; p.ncone = ncone;
+    p.con_static = 7;
+    for (const auto& bl : blocks) p.con_static = bl.per_knot ? 0 : p.con_static;
+    if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) p.con_static &= atoi(e);  // diagnostic switch
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
