@@ -43,10 +43,10 @@
 
 // tuning knobs (defaults = the shipped configuration; overridable with -D for experiments)
 #ifndef ALTRO_PD_OPEN
-#define ALTRO_PD_OPEN 4      // knots of operand prefetch in the open-loop rollout
+#define ALTRO_PD_OPEN 8    // knots of prefetch in the open-loop rollout (measured 2..8: 8 best once the loop is branch-free)
 #endif
 #ifndef ALTRO_PD_CLOSED
-#define ALTRO_PD_CLOSED 4    // ... in the closed-loop rollout
+#define ALTRO_PD_CLOSED 2  // knots of prefetch in the closed-loop rollout (2..6 measured: 6 spills)
 #endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
