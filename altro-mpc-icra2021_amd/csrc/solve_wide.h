@@ -451,7 +451,9 @@ struct Solver {
     int ct;
   };
 
-  __device__ __forceinline__ KnotLd load_knot(int k, bool term, bool open, const double* Xs, const double* Us) const {
+  // mode 0: closed-loop rollout (state of plane cur, gains); 1: open-loop rollout; 2: backward pass (state, no gains)
+  __device__ __forceinline__ KnotLd load_knot(int k, bool term, int mode, const double* Xs, const double* Us) const {
+    const bool open = mode == 1, need_k = mode == 0;
     KnotLd d;
     const bool bx = box_at(k);
     d.xs = d.us = d.dgv = d.xr = d.ur = d.lxh = d.lxl = d.luh = d.lul = d.lam = d.bc = 0.0;
@@ -473,7 +475,7 @@ struct Solver {
         d.luh = Lbi[((size_t)k * 2 + 0) * nz + n + T];
         d.lul = Lbi[((size_t)k * 2 + 1) * nz + n + T];
       }
-      if (!open) {
+      if (need_k) {
         d.dgv = dgi[(size_t)k * m + T];
         const double* Kk = Kgi + (size_t)k * n * m + T;
 #pragma unroll
@@ -535,10 +537,10 @@ struct Solver {
     double J = 0.0, viol = 0.0;
     bool lim = false;
     double xb = T < n ? x0i[T] : 0.0;
-    KnotLd d = load_knot(0, false, open, Xs, Us);
+    KnotLd d = load_knot(0, false, open ? 1 : 0, Xs, Us);
     for (int k = 0; k < N - 1; ++k) {
       const bool last = k == N - 2;
-      const KnotLd dn = load_knot(k + 1, last, open, Xs, Us);   // knot N-1 is the terminal knot
+      const KnotLd dn = load_knot(k + 1, last, open ? 1 : 0, Xs, Us);   // knot N-1 is the terminal knot
       if (T < n) {
         zb[T] = xb;
         if (!open) dxv[T] = xb - d.xs;
@@ -612,28 +614,25 @@ struct Solver {
 
   // cost_expansion! at knot k of plane cur: gradient qz, Hessian diagonal hz (padded z layout), and
   // for the generic rows the tables Ac, DA = diag(I_mu) Ac with A'g already added to qz
-  __device__ __forceinline__ void expansion(int k, bool term) {
-    const double* Xs = Xp(cur);
-    const double* Us = Up(cur);
+  __device__ __forceinline__ void expansion(int k, bool term, const KnotLd& d) {
     const bool bx = box_at(k);
     if (T < n) {
-      const double x = Xs[(size_t)k * n + T];
+      const double x = d.xs;
       zb[T] = x;
       const double w = term ? cwfx : cwx;
-      double q = w * (x - Xri[(size_t)(kref + k) * n + T]), h = w;
-      if (bx) box_expand(mu, x, cxmax, cxmin, Lbi[((size_t)k * 2) * nz + T], Lbi[((size_t)k * 2 + 1) * nz + T], q, h);
+      double q = w * (x - d.xr), h = w;
+      if (bx) box_expand(mu, x, cxmax, cxmin, d.lxh, d.lxl, q, h);
       qz[T] = q;
       hz[T] = h;
     }
     if (T < m) {
       double q = 0.0, h = 0.0, u = 0.0;
       if (!term) {
-        const int j = n + T;
-        u = Us[(size_t)k * m + T];
+        u = d.us;
         const double w = cwu;
-        q = w * (u - Uri[(size_t)(kref + k) * m + T]);
+        q = w * (u - d.ur);
         h = w;
-        if (bx) box_expand(mu, u, cumax, cumin, Lbi[((size_t)k * 2) * nz + j], Lbi[((size_t)k * 2 + 1) * nz + j], q, h);
+        if (bx) box_expand(mu, u, cumax, cumin, d.luh, d.lul, q, h);
       }
       zb[np + T] = u;
       qz[np + T] = q;
@@ -646,10 +645,10 @@ struct Solver {
       if (T < Pp) {
         double g = 0.0, D = 0.0;
         if (T < Pn) {
-          ct = P.ctype[(size_t)k * Pn + T];
+          ct = d.ct;
           if (ct != 0) {
             v = row_value(k, T, term);
-            lam = Lci[(size_t)k * Pn + T];
+            lam = d.lam;
             if (ct != 3) {
               const bool act = (ct == 1) || (v >= 0.0) || (lam > 0.0);
               g = lam + (act ? mu * v : 0.0);
@@ -781,7 +780,7 @@ struct Solver {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
-    expansion(N - 1, true);
+    expansion(N - 1, true, load_knot(N - 1, true, 2, Xp(cur), Up(cur)));
     if (T < n) {
       S[T * lds + T] = hz[T];
       sv[T] = qz[T];
@@ -795,10 +794,13 @@ struct Solver {
     dV1 = 0.0;
     dV2 = 0.0;
     wsync();
+    KnotLd kd = load_knot(N - 2, false, 2, Xp(cur), Up(cur));
     for (int k = N - 2; k >= 0; --k) {
       WSTAMP(const long long b0 = wstamp();)
+      const KnotLd kdn = load_knot(k > 0 ? k - 1 : 0, false, 2, Xp(cur), Up(cur));  // operands of the next knot, one knot ahead
       if (P.ltv) load_dyn(k);
-      expansion(k, false);  // ends with a barrier
+      expansion(k, false, kd);  // ends with a barrier
+      kd = kdn;
       WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
       // Q_z = l_z + [A B]' s
       for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
