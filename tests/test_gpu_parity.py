@@ -766,6 +766,12 @@ def test_error_paths():
     with pytest.raises(altro.AltroError) as e:
         altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
     assert e.value.code == altro._lib.ERR_UNSUPPORTED
+    # n = 64 with m = 20: the padded knot matrices exceed the 160 KB of LDS of a CU
+    pb = altro.problems.gen_random_linear_batch(1, n=64, m=20, N=5, steps=1)
+    sv = altro.ALTROSolver(altro.mpc.gen_tracking_problem(pb))
+    with pytest.raises(altro.AltroError) as e:
+        altro.solve(sv)
+    assert e.value.code == altro._lib.ERR_UNSUPPORTED
     # cones of dimension 5 fit neither kernel
     pb = altro.problems.gen_random_linear_batch(2, n=12, m=6, N=9, steps=1)
     prob = altro.mpc.gen_tracking_problem(pb)
