@@ -526,10 +526,107 @@ struct Solver {
     }
   }
 
+  // branch-free AL cost of one element (selects only): same value as lane_cost
+  static __device__ __forceinline__ double lane_cost_sel(double w, double z, double zr, double zmx, double zmn, double lhi, double llo,
+                                                         double mu, bool on, bool box_on, double& viol) {
+    const double e = z - zr;
+    double J = 0.5 * w * e * e;
+    const double chi = z - zmx, clo = zmn - z;
+    const bool bh = on & box_on & (zmx < 1e300), bl = on & box_on & (zmn > -1e300);
+    const bool ah = (chi >= 0.0) | (lhi > 0.0), al = (clo >= 0.0) | (llo > 0.0);
+    J += bh ? lhi * chi + (ah ? 0.5 * mu * chi * chi : 0.0) : 0.0;
+    J += bl ? llo * clo + (al ? 0.5 * mu * clo * clo : 0.0) : 0.0;
+    viol = fmax(viol, bh ? chi : 0.0);
+    viol = fmax(viol, bl ? clo : 0.0);
+    return on ? J : 0.0;
+  }
+
+  // Rollout for the common problem class -- time-invariant dynamics, box constraints only -- written
+  // without a single branch in the knot body (clamped unconditional loads, selects, LDS trash slot):
+  // with branches hipcc waits vmcnt(0) at the first use after a join and the operands requested for
+  // knot k+1 overlap with nothing (the generic body has ~60 of them).  CLOSED is a template argument.
+  template <bool CLOSED>
+  __device__ __forceinline__ RollOut rollout_simple(double alpha) {
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    double* Xd = CLOSED ? Xp(cur ^ 1) : Xp(cur);
+    double* Ud = CLOSED ? Up(cur ^ 1) : Up(cur);
+    const bool isx = T < n, isu = T < m;
+    const int Tn = isx ? T : n - 1, Tm = isu ? T : m - 1;
+    double* zslot = zb + (isx ? T : nzp);         // lanes without a state element write the trash word zb[nzp] (= qz[0], dead here)
+    double* uslot = zb + (isu ? np + T : nzp);
+    double* dslot = isx ? dxv + T : zb + nzp;
+    const double* grow = G + Tn * ly.ldg;
+    const double fT = fk(0)[Tn];
+    double J = 0.0, viol = 0.0;
+    bool lim = false;
+    double xb = isx ? x0i[Tn] : 0.0;
+    struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
+    auto ld = [&](int k) {
+      Ld d;
+      const int ku = k < N - 1 ? k : N - 2;     // the terminal knot has no control: clamp, its control terms are switched off
+      d.xs = Xs[(size_t)k * n + Tn];
+      d.xr = Xri[(size_t)(kref + k) * n + Tn];
+      d.lxh = Lbi[((size_t)k * 2 + 0) * nz + Tn];
+      d.lxl = Lbi[((size_t)k * 2 + 1) * nz + Tn];
+      d.us = Us[(size_t)ku * m + Tm];
+      d.ur = Uri[(size_t)(kref + ku) * m + Tm];
+      d.luh = Lbi[((size_t)ku * 2 + 0) * nz + n + Tm];
+      d.lul = Lbi[((size_t)ku * 2 + 1) * nz + n + Tm];
+      d.dgv = CLOSED ? dgi[(size_t)ku * m + Tm] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) d.kp[u] = CLOSED ? Kgi[(size_t)ku * n * m + (size_t)(u < n ? u : n - 1) * m + Tm] : 0.0;
+      return d;
+    };
+    Ld d = ld(0);
+    for (int k = 0; k < N - 1; ++k) {
+      const Ld dn = ld(k + 1);
+      const bool bx = box_at(k);
+      *zslot = xb;
+      if (CLOSED) *dslot = xb - d.xs;
+      if (isx) Xd[(size_t)k * n + T] = xb;
+      wsync();
+      double acc = d.us;
+      if (CLOSED) {
+        acc += alpha * d.dgv;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += d.kp[u] * dxv[u];
+        if (n > 16) acc = dot_strided(Kgi + (size_t)k * n * m + (size_t)16 * m + Tm, m, dxv + 16, n - 16, acc);
+        if (isu) Ud[(size_t)k * m + T] = acc;
+      }
+      const double uv = acc;
+      *uslot = uv;
+      wsync();
+      J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
+      J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
+      lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
+      const double xn = dot_lds(grow, 1, zb, 1, nzp, fT);
+      wsync();
+      xb = isx ? xn : 0.0;
+      d = dn;
+    }
+    *zslot = xb;
+    if (isx) Xd[(size_t)(N - 1) * n + T] = xb;
+    wsync();
+    J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
+    lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));
+    __syncthreads();
+    RollOut r;
+    r.J = wave_sum(J);
+    r.cmax = wave_max(viol);
+    r.limit = wave_any(lim);
+    return r;
+  }
+
+  __device__ __forceinline__ RollOut rollout(bool open, double alpha) {
+    if (Pn == 0 && !P.ltv) return open ? rollout_simple<false>(0.0) : rollout_simple<true>(alpha);
+    return rollout_generic(open, alpha);
+  }
+
   // rollout!(solver[, alpha]): open loop in place on plane cur, or closed loop from plane cur into
   // plane cur^1 (oracle rollout_open / rollout_alpha), fused with cost! and max_violation.  The
   // per-lane operands of knot k+1 are requested before knot k is processed.
-  __device__ __forceinline__ RollOut rollout(bool open, double alpha) {
+  __device__ __forceinline__ RollOut rollout_generic(bool open, double alpha) {
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     double* Xd = open ? Xp(cur) : Xp(cur ^ 1);
