@@ -45,6 +45,7 @@ struct Params {
   int* cur;             // [B]
   double *Lb, *Lc, *mu; // [B][N][2][n+m], [B][N][Pn], [B]
   double *Kg, *dg;      // [B][N-1][n][m] (m x n column-major), [B][N-1][m]
+  double* trash;        // [B][64] sink for the stores of lanes that hold no element (keeps loop bodies branch-free)
   int *iters, *iters_outer, *status;
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
   long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok;
@@ -556,6 +557,7 @@ struct Solver {
     double* zslot = zb + (isx ? T : nzp);         // lanes without a state element write the trash word zb[nzp] (= qz[0], dead here)
     double* uslot = zb + (isu ? np + T : nzp);
     double* dslot = isx ? dxv + T : zb + nzp;
+    double* gtrash = P.trash + (size_t)inst * 64 + T;
     const double* grow = G + Tn * ly.ldg;
     const double fT = fk(0)[Tn];
     double J = 0.0, viol = 0.0;
@@ -584,7 +586,7 @@ struct Solver {
       const bool bx = box_at(k);
       *zslot = xb;
       if (CLOSED) *dslot = xb - d.xs;
-      if (isx) Xd[(size_t)k * n + T] = xb;
+      *(isx ? Xd + (size_t)k * n + T : gtrash) = xb;
       wsync();
       double acc = d.us;
       if (CLOSED) {
@@ -592,7 +594,7 @@ struct Solver {
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc += d.kp[u] * dxv[u];
         if (n > 16) acc = dot_strided(Kgi + (size_t)k * n * m + (size_t)16 * m + Tm, m, dxv + 16, n - 16, acc);
-        if (isu) Ud[(size_t)k * m + T] = acc;
+        *(isu ? Ud + (size_t)k * m + T : gtrash) = acc;
       }
       const double uv = acc;
       *uslot = uv;
@@ -606,7 +608,7 @@ struct Solver {
       d = dn;
     }
     *zslot = xb;
-    if (isx) Xd[(size_t)(N - 1) * n + T] = xb;
+    *(isx ? Xd + (size_t)(N - 1) * n + T : gtrash) = xb;
     wsync();
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
     lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));

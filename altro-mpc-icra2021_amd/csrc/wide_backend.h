@@ -55,7 +55,7 @@ struct WideBackend {
   // device
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
-         *mu = nullptr, *Kg = nullptr, *dg = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr;
+         *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr;
   int *cur = nullptr, *ctype = nullptr, *rowk0 = nullptr, *rowk1 = nullptr, *rowc0 = nullptr, *rowcp = nullptr, *iters = nullptr, *iters_outer = nullptr,
       *status = nullptr, *noise_grp = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr, *noise = nullptr,
@@ -113,7 +113,7 @@ struct WideBackend {
 #define DA_(p, c) if ((rc = dalloc(&p, (c)))) return rc
     DA_(wd, z); DA_(wf, n); DA_(zmin, z); DA_(zmax, z);
     DA_(x0, B * n); DA_(X, B * 2 * N * n); DA_(U, B * 2 * (N - 1) * m); DA_(cur, B);
-    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m);
+    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64);
     DA_(iters, B); DA_(iters_outer, B); DA_(status, B); DA_(cost, B); DA_(cmax, B);
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
     DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B);
@@ -134,7 +134,7 @@ struct WideBackend {
   void destroy() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
-    void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, AconT, bcon, stage, cur, ctype,
+    void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
                     n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok};
     for (void* p : ptrs)
@@ -363,7 +363,7 @@ struct WideBackend {
     p.con_static = 7;
     for (const auto& bl : blocks) p.con_static = bl.per_knot ? 0 : p.con_static;
     if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) p.con_static &= atoi(e);  // diagnostic switch
-    p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg;
+    p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
     p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok;
