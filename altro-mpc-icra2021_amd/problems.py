@@ -343,7 +343,9 @@ def quadruped_continuous_dynamics(x, u, feet, contacts, inertia, mass):
 def quadruped_linearize(xr, ur, feet, contacts, inertia, mass, dt, eps=1e-6):
     """A_k, B_k, d_k of update_dynamics_matrices! (altro_solver.jl:5-37): Jacobians of the
     continuous dynamics at (x_ref, u_ref) (central differences here, ForwardDiff there), affine
-    remainder d = f(x_ref,u_ref) - A x_ref - B u_ref, forward-Euler discretisation."""
+    remainder d = f(x_ref,u_ref) - A x_ref - B u_ref, forward-Euler discretisation.  (The reference's
+    rollouts use a shortcut of this model, linearized_dynamics.jl:69-96; the solvers here roll out the
+    full affine model.)"""
     f0 = quadruped_continuous_dynamics(xr, ur, feet, contacts, inertia, mass)
     Ac = np.zeros((12, 12))
     Bc = np.zeros((12, 12))
