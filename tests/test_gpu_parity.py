@@ -746,6 +746,40 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
+@pytest.mark.parametrize("n,m", [(12, 4), (12, 6)])
+def test_option_fuzz_matches_oracle(oracle, n, m):
+    """Random solver options on random problems, cold starts far from the reference: iteration caps that end
+    solves in MAX_ITERATIONS / MAX_ITERATIONS_OUTER, short line searches (failed searches and the
+    regularisation bumps that follow), dual and penalty caps, reset_duals on and off -- every status,
+    count and trace must equal the oracle's, on the 16-lane kernel (12,4) and on the wide kernel (12,6)."""
+    rng = np.random.default_rng(100 + m)
+    B, N = 6, 20
+    statuses = set()
+    for trial in range(10):
+        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=1, seed=1000 + trial)
+        prob = altro.mpc.gen_tracking_problem(pb)
+        prob.x0 = prob.x0 + rng.standard_normal(prob.x0.shape) * rng.uniform(0.5, 10.0)
+        opts = dict(cost_tolerance=10.0 ** rng.uniform(-8, -3), constraint_tolerance=10.0 ** rng.uniform(-8, -3),
+                    penalty_initial=10.0 ** rng.uniform(-1, 4), penalty_scaling=float(rng.choice([2.0, 10.0, 100.0])),
+                    penalty_max=10.0 ** rng.uniform(4, 8), dual_max=10.0 ** rng.uniform(0, 8),
+                    iterations=int(rng.choice([3, 8, 40, 1000])), iterations_inner=int(rng.choice([2, 5, 300])),
+                    iterations_outer=int(rng.choice([1, 2, 4, 30])), iterations_linesearch=int(rng.choice([0, 2, 20])),
+                    reset_duals=int(rng.integers(0, 2)))
+        opts["cost_tolerance_intermediate"] = opts["cost_tolerance"] * float(rng.choice([1.0, 10.0]))
+        sv = altro.ALTROSolver(prob, altro.SolverOptions(**opts))
+        altro.solve(sv)
+        altro.solve(sv)                      # a second solve from the first one's result (warm duals when reset_duals = 0)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            o = make_oracle(oracle, pb, b, opts=opts)
+            o.set_initial_state(prob.x0[b])
+            o.solve()
+            so = o.solve()
+            statuses.add(so.status)
+            check_against_oracle(st, X, U, b, o, so)
+    assert len(statuses) >= 3, statuses       # the fuzz reached several termination statuses
+
+
 def test_benchmark_script_functions_run():
     """benchmarks.py restates the reference's four benchmark scripts as functions; small batches here."""
     from altro_mpc_icra2021_amd import benchmarks as Bm
