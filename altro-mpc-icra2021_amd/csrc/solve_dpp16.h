@@ -46,7 +46,7 @@
 #define ALTRO_PD_OPEN 8    // knots of prefetch in the open-loop rollout (measured 2..8: 8 best once the loop is branch-free)
 #endif
 #ifndef ALTRO_PD_CLOSED
-#define ALTRO_PD_CLOSED 2  // knots of prefetch in the closed-loop rollout (2..6 measured: 6 spills)
+#define ALTRO_PD_CLOSED 4  // knots of prefetch in the closed-loop rollout (2..8 measured with the butterfly gain sums: 4 best)
 #endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
@@ -134,6 +134,13 @@ __device__ __forceinline__ double bcast(double v) {
   // v_mov_b64_dpp row_newbcast:K -- value of lane K of this lane's 16-lane row
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);
 }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  // two v_mov_b32_dpp: quad_perm 0x00..0xFF, row_ror:n 0x120 + n (within the 16-lane row)
+  return __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
 
 template <int I, int E, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -463,7 +470,7 @@ struct Solver {
 
   struct KnotIn {
     double z, zr, lhi, llo;
-    double kcol[NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] in kcol[a]
+    double kcol[NU <= 4 ? 4 : NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] (slot order: see rollout)
     double lc;        // dual of this lane's constraint row (CONES)
   };
 
@@ -503,6 +510,19 @@ struct Solver {
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
 
+    // NU <= 4: slot s of lane l holds gain row A = ((s ^ (l & 3)) - NX) & 3, the order in which the
+    // xor butterfly of `stage` leaves the sum of row A in lane NX + A (and d[A] in that lane's slot 0)
+    unsigned kofs[4] = {0u, 0u, 0u, 0u};
+    bool kval[4] = {false, false, false, false};
+    if constexpr (!OPEN && NU <= 4) {
+      sfor<0, 4>([&](auto c) {
+        constexpr int S = decltype(c)::value;
+        const int A = ((S ^ (j & 3)) - NX) & 3;
+        kval[S] = is_x & (A < NU);
+        kofs[S] = (unsigned)imin(A, NU - 1) * LW;
+      });
+    }
+
     // operands of stage knot k (k clamped to 0..N-2 by the callers)
     auto load = [&](int k, KnotIn& in, ConK& ck) {
       const int ku = imin(k + 1, N - 2);
@@ -513,7 +533,11 @@ struct Solver {
       in.lhi = ldg(P.Lb, lb_at(kk, 0));
       in.llo = ldg(P.Lb, lb_at(kk, 1));
       if constexpr (!OPEN) {
-        sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
+        if constexpr (NU <= 4) {
+          sfor<0, 4>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, 0) + kofs[decltype(c)::value]); });
+        } else {
+          sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
+        }
       }
       in.lc = 0.0;
       if constexpr (CONES) {
@@ -537,22 +561,36 @@ struct Solver {
       } else {
         // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
         const double dx = is_x ? (xb - in.z) : 0.0;
-        double prod[NU], acc[NU][3];
-        sfor<0, NU>([&](auto a) {
-          constexpr int A = decltype(a)::value;
-          prod[A] = is_x ? in.kcol[A] * dx : 0.0;
-          acc[A][0] = acc[A][1] = acc[A][2] = 0.0;
-        });
-        const double one = 1.0;
-        Blk<NX, NU>::KDXT(acc, prod, one);
-        double du = (acc[0][0] + acc[0][1]) + acc[0][2];
-        double dff = in.kcol[0];
-        sfor<1, NU>([&](auto a) {
-          constexpr int A = decltype(a)::value;
-          const double da = (acc[A][0] + acc[A][1]) + acc[A][2];
-          du = (j == NX + A) ? da : du;
-          dff = (j == NX + A) ? in.kcol[A] : dff;
-        });
+        double du, dff = in.kcol[0];
+        if constexpr (NU <= 4) {
+          // four row sums over the x lanes in 15 VALU: lanes trade two slots with lane^1, one with
+          // lane^2 (afterwards every lane of a quad holds the quad's part of row (l&3)-NX), then the
+          // four quads are added by two rotations.  Lane NX + A ends with sum_j K[A][j] dx_j.
+          double p[4];
+          sfor<0, 4>([&](auto c) { p[decltype(c)::value] = kval[decltype(c)::value] ? in.kcol[decltype(c)::value] * dx : 0.0; });
+          const double n0 = p[0] + dpp_mov<DPP_XOR1>(p[1]);
+          const double n2 = p[2] + dpp_mov<DPP_XOR1>(p[3]);
+          double q = n0 + dpp_mov<DPP_XOR2>(n2);
+          q += dpp_mov<DPP_ROR8>(q);
+          q += dpp_mov<DPP_ROR4>(q);
+          du = q;
+        } else {
+          double prod[NU], acc[NU][3];
+          sfor<0, NU>([&](auto a) {
+            constexpr int A = decltype(a)::value;
+            prod[A] = is_x ? in.kcol[A] * dx : 0.0;
+            acc[A][0] = acc[A][1] = acc[A][2] = 0.0;
+          });
+          const double one = 1.0;
+          Blk<NX, NU>::KDXT(acc, prod, one);
+          du = (acc[0][0] + acc[0][1]) + acc[0][2];
+          sfor<1, NU>([&](auto a) {
+            constexpr int A = decltype(a)::value;
+            const double da = (acc[A][0] + acc[A][1]) + acc[A][2];
+            du = (j == NX + A) ? da : du;
+            dff = (j == NX + A) ? in.kcol[A] : dff;
+          });
+        }
         const double ub = in.z + du + dff;  // alpha = 1
         zb = is_x ? xb : ub;
         changed = changed | ((is_x | is_u) & (zb != in.z));
