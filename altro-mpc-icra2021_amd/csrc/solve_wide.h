@@ -175,7 +175,16 @@ __device__ __forceinline__ long long wstamp() {
 #else
 #define WSTAMP(x)
 #endif
+#ifndef ALTRO_WIDE_WAVES_SMALL
+// waves per SIMD the m <= 8 instantiations are compiled for.  Measured at 2 (256 registers): 1.1 KB of
+// scratch per lane and 10-20 % slower than one wave with 512 registers (n = 16: 0.55 vs 0.60 M solves/s)
+#define ALTRO_WIDE_WAVES_SMALL 1
+#endif
 
+// MC: control-size class the instantiation is compiled for.  4/8/12/16: m <= MC, Quu is factored in
+// registers (factor_solve_regs<MC>); 0: m > 16, the LDS factorisation.  One kernel that switched
+// between all of them at run time needed the registers of the largest (512, one wave per SIMD).
+template <int MC>
 struct Solver {
   const Params& P;
   const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
@@ -924,17 +933,12 @@ struct Solver {
         wsync();
       }
       WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
-      if (m > 16)
+      if constexpr (MC == 0)
         for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];  // the LDS solve works in place on a copy of [Qux | Qu]
       if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
       wsync();
-      if (m <= 16) {
-        bool fail;
-        if (m <= 4) fail = factor_solve_regs<4>();
-        else if (m <= 8) fail = factor_solve_regs<8>();
-        else if (m <= 12) fail = factor_solve_regs<12>();
-        else fail = factor_solve_regs<16>();
-        if (fail) return true;
+      if constexpr (MC > 0) {
+        if (factor_solve_regs<MC>()) return true;
       } else {
         // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
         for (int j = 0; j < m; ++j) {
@@ -1293,18 +1297,34 @@ struct Solver {
   }
 };
 
-__global__ void __launch_bounds__(64) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
+// waves per SIMD the register allocator is held to, per control-size class
+constexpr int wide_waves(int MC) { return (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
+
+template <int MC>
+__global__ void __launch_bounds__(64, wide_waves(MC)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
-  Solver s(P, lds);
+  Solver<MC> s(P, lds);
   s.run(mpc, first_step, nsteps);
 }
 
 // the separate shift_fill call of the fine-grained ABI
 __global__ void __launch_bounds__(64) wide_shift_kernel(Params P, int primal, int dual) {
   extern __shared__ double lds[];
-  Solver s(P, lds);
+  Solver<0> s(P, lds);
   s.cur = P.cur[s.inst];
   s.shift(primal != 0, dual != 0);
+}
+
+typedef void (*wide_kernel_t)(Params, int, int, int);
+inline int wide_class(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : 0; }
+inline wide_kernel_t wide_kernel_for(int m) {
+  switch (wide_class(m)) {
+    case 4: return wide_kernel<4>;
+    case 8: return wide_kernel<8>;
+    case 12: return wide_kernel<12>;
+    case 16: return wide_kernel<16>;
+    default: return wide_kernel<0>;
+  }
 }
 
 }  // namespace altro_wide

@@ -384,7 +384,7 @@ struct WideBackend {
     con_locked = true;
     const size_t bytes = lds_bytes();
     if (bytes > 160 * 1024) WFAIL(ALTRO_ERR_UNSUPPORTED, "problem does not fit the 160 KB of LDS of one CU");
-    WCHK(hipFuncSetAttribute((const void*)wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    WCHK(hipFuncSetAttribute((const void*)wide_kernel_for(d.m), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     WCHK(hipFuncSetAttribute((const void*)wide_shift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return ALTRO_OK;
   }
@@ -413,7 +413,7 @@ struct WideBackend {
         hist.push_back(e);
       }
     WCHK(hipEventRecord(hist[hist_used], stream));
-    hipLaunchKernelGGL(wide_kernel, dim3(d.batch), dim3(64), lds_bytes(), stream, params(), mpc, first_step, nsteps);
+    hipLaunchKernelGGL(wide_kernel_for(d.m), dim3(d.batch), dim3(64), lds_bytes(), stream, params(), mpc, first_step, nsteps);
     WCHK(hipGetLastError());
     WCHK(hipEventRecord(hist[hist_used + 1], stream));
     hist_used += 2;
