@@ -192,6 +192,34 @@ struct Solver {
   double *G, *S, *W, *Hux, *Kl, *Huu, *Ac, *DA;
   double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr, *cvv, *cll, *Hc;
   int myc0 = 0, mycp = 0;
+  // e = T + 64 t written as q * d + r without a division per element (an integer division is ~40
+  // VALU instructions, and the element loops below ran one per 64 elements per knot): the lane's
+  // start (T / d, T % d) and the step (64 / d, 64 % d) are worked out once per launch.
+  struct Stride {
+    int q0, r0, dq, dr, d;
+  };
+  struct Walk {
+    int q, r;
+  };
+  Stride by_n, by_m, by_P;
+  static __device__ __forceinline__ Stride make_stride(int T, int d) {
+    Stride s;
+    s.d = d > 0 ? d : 1;
+    s.q0 = T / s.d;
+    s.r0 = T - s.q0 * s.d;
+    s.dq = 64 / s.d;
+    s.dr = 64 - s.dq * s.d;
+    return s;
+  }
+  static __device__ __forceinline__ Walk start(const Stride& s) { return Walk{s.q0, s.r0}; }
+  static __device__ __forceinline__ void step(const Stride& s, Walk& w) {
+    w.q += s.dq;
+    w.r += s.dr;
+    if (w.r >= s.d) {
+      w.r -= s.d;
+      ++w.q;
+    }
+  }
   double *Xi, *Ui, *Lbi, *Lci, *Kgi, *dgi, *x0i;
   const double *Xri, *Uri;
   int cur, kref;
@@ -211,6 +239,9 @@ struct Solver {
     zb = v; v += nzp; qz = v; v += nzp; hz = v; v += nzp; qv = v; v += nzp; v += 2 * nzp;
     dxv = v; v += np; sv = v; v += np; gr = v; v += Pp + 4; Dr = v; v += Pp + 4; cvv = v; v += Pp + 4; cll = v; v += Pp + 4;
     Hc = v;  // [Pp + 4][4] Hessian rows of the cone blocks
+    by_n = make_stride(T, n);
+    by_m = make_stride(T, m);
+    by_P = make_stride(T, Pn);
     myc0 = (T < Pn) ? P.rowc0[T] : 0;
     mycp = (T < Pn) ? P.rowcp[T] : 0;
     const size_t b = inst;
@@ -308,8 +339,9 @@ struct Solver {
   // time-invariant constraint data: the table lives in Ac for the whole launch (row r taken from the
   // first knot of its range); rows that are inactive at a knot get zero weights, so they do no harm
   __device__ __forceinline__ void build_static_Ac() {
-    for (int e = T; e < nz * Pn; e += 64) {
-      const int j = e / Pn, r = e - j * Pn;
+    Walk w = start(by_P);
+    for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
+      const int j = w.q, r = w.r;
       const int c = j < n ? j : np + (j - n);
       Ac[r * ly.ldg + c] = P.AconT[((size_t)P.rowk0[r] * nz + j) * Pn + r];
     }
@@ -694,14 +726,10 @@ struct Solver {
 
   __device__ __forceinline__ void load_dyn(int k) {
     const double *A_ = Ak(k), *B_ = Bk(k);
-    for (int e = T; e < n * n; e += 64) {
-      const int j = e / n, i = e - j * n;
-      G[i * ly.ldg + j] = A_[e];
-    }
-    for (int e = T; e < n * m; e += 64) {
-      const int a = e / n, i = e - a * n;
-      G[i * ly.ldg + np + a] = B_[e];
-    }
+    Walk w = start(by_n);
+    for (int e = T; e < n * n; e += 64, step(by_n, w)) G[w.r * ly.ldg + w.q] = A_[e];
+    w = start(by_n);
+    for (int e = T; e < n * m; e += 64, step(by_n, w)) G[w.r * ly.ldg + np + w.q] = B_[e];
   }
 
   static __device__ __forceinline__ void box_expand(double mu, double z, double zmx, double zmn, double lhi, double llo,
@@ -788,8 +816,9 @@ struct Solver {
       }
       const double* At = P.AconT + (size_t)k * nz * Pn;
       const bool resident = (P.con_static & 4) && !term;
-      for (int e = T; e < nz * Pn; e += 64) {
-        const int j = e / Pn, r = e - j * Pn;
+      Walk w = start(by_P);
+      for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
+        const int j = w.q, r = w.r;
         const int c = j < n ? j : np + (j - n);
         const double a = resident ? Ac[r * ly.ldg + c] : ((term && j >= n) ? 0.0 : At[e]);
         if (!resident) Ac[r * ly.ldg + c] = a;
@@ -797,8 +826,9 @@ struct Solver {
       }
       wsync();
       if (P.ncone > 0) {  // cone rows: DA = H_block * A over the rows of the cone
-        for (int e = T; e < nz * Pn; e += 64) {
-          const int j = e / Pn, r = e - j * Pn;
+        w = start(by_P);
+        for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
+          const int j = w.q, r = w.r;
           const int cp = P.rowcp[r];
           if (cp > 0) {
             const int c0 = P.rowc0[r], c = j < n ? j : np + (j - n);
@@ -997,8 +1027,9 @@ struct Solver {
         sv[T] = acc;
       }
       wsync();
-      for (int e = T; e < n * n; e += 64) {  // S <- (S + S')/2
-        const int i = e / n, j = e - i * n;
+      Walk w = start(by_n);
+      for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
+        const int i = w.q, j = w.r;
         if (i > j) {
           const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
           S[i * lds + j] = v;
@@ -1006,10 +1037,8 @@ struct Solver {
         }
       }
       double* Kk = Kgi + (size_t)k * n * m;
-      for (int e = T; e < n * m; e += 64) {
-        const int j = e / m, a = e - j * m;
-        Kk[e] = Kl[a * ldh + j];
-      }
+      w = start(by_m);
+      for (int e = T; e < n * m; e += 64, step(by_m, w)) Kk[e] = Kl[w.r * ldh + w.q];
       if (T < m) dgi[(size_t)k * m + T] = Kl[T * ldh + np];
       wsync();
       WSTAMP(t_d += wstamp() - b3;)
