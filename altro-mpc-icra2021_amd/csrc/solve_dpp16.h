@@ -509,6 +509,11 @@ struct Solver {
     const bool wr_l = OPEN && shift && take;  // shifted duals are written back
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
+    // Pinned in a register: hipcc otherwise re-loads this select-of-two-kernel-arguments inside the
+    // knot loop (a rematerialised global_load), and the in-order vmcnt wait on that load drains the
+    // whole prefetch ring once or twice per group of knots.
+    double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
+    asm volatile("" : "+v"(lim));
 
     // NU <= 4: slot s of lane l holds gain row A = ((s ^ (l & 3)) - NX) & 3, the order in which the
     // xor butterfly of `stage` leaves the sum of row A in lane NX + A (and d[A] in that lane's slot 0)
@@ -606,7 +611,6 @@ struct Solver {
         viol = fmax(viol, e.viol);
         if constexpr (OPEN) stg(P.Lc, at((wr_l & act) ? k : P.N), in.lc);
       }
-      const double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
       limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
       Blk<NX, NU>::GZ(acc4, zb, grow);

@@ -20,3 +20,11 @@ print("wave cycles: mean %.2fM  p50 %.2fM  p99 %.2fM  max %.2fM  -> mean/max = %
 print("mean wave  :", " ".join("%s %.2fM" % (n, wcs[:, i].mean() / 1e6) for i, n in enumerate(names)))
 st = altro.stats(mp.solver)
 print("kernel ms %.2f" % st.tsolve_ms)
+# the slowest waves: which phase carries their extra time, and how many turns of the wave loop they took
+order = np.argsort(-wcs[:, 0])[:5]
+nit4 = ni.reshape(-1, 4)
+for w in order:
+    print("wave %5d: %s | row iterations %s" % (w, " ".join("%s %.2fM" % (n, wcs[w, i] / 1e6) for i, n in enumerate(names)), nit4[w].tolist()))
+tot_it = nit4.max(1)
+print("cycles per wave-iteration (total / max-of-4 iterations): mean %.0fk, slowest five %s" % (
+    (wcs[:, 0] / tot_it).mean() / 1e3, ", ".join("%.0fk" % (wcs[w, 0] / tot_it[w] / 1e3) for w in order)))
