@@ -471,7 +471,7 @@ struct Solver {
   struct KnotIn {
     double z, zr, lhi, llo;
     double kcol[NU <= 4 ? 4 : NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] (slot order: see rollout)
-    double lc;        // dual of this lane's constraint row (CONES)
+    double lc, lcn;   // dual of this lane's constraint row at the knot and at the next one (CONES)
   };
 
   // rollout!(solver[, alpha]) fused with cost!(obj, Z̄) and max_violation.
@@ -545,11 +545,14 @@ struct Solver {
         }
       }
       in.lc = 0.0;
+      in.lcn = 0.0;
       if constexpr (CONES) {
         con_load(k, ck);
-        // shifted read stays inside the row's own knot range; lanes without a row (k1 = -1) read knot k
-        const int kc = (shl & (ck.cm.type != CT_NONE)) ? imax(imin(k + 1, ck.cm.k1), 0) : k;
-        in.lc = ldg(P.Lc, at(kc));
+        // the shifted read (knot k + 1 while that is inside the row's own range) is chosen in `stage`:
+        // an address that depends on the row's metadata would make this a dependent load, and the
+        // in-order vmcnt wait in front of it drains the whole prefetch ring
+        in.lc = ldg(P.Lc, at(k));
+        if constexpr (OPEN) in.lcn = ldg(P.Lc, at(imin(k + 1, N - 1)));
       }
     };
 
@@ -606,10 +609,12 @@ struct Solver {
       if constexpr (CONES) {
         const bool act = con_act(ck.cm, k);
         const double v = con_value(zb, ck.arow, ck.brow);
-        const ConeEval e = cone_eval<false>(v, act ? in.lc : 0.0, mu, ck.cm, act, dmax, so2);
+        double lck = in.lc;
+        if constexpr (OPEN) lck = (shl & (k + 1 <= ck.cm.k1)) ? in.lcn : in.lc;
+        const ConeEval e = cone_eval<false>(v, act ? lck : 0.0, mu, ck.cm, act, dmax, so2);
         Jacc += e.cost;
         viol = fmax(viol, e.viol);
-        if constexpr (OPEN) stg(P.Lc, at((wr_l & act) ? k : P.N), in.lc);
+        if constexpr (OPEN) stg(P.Lc, at((wr_l & act) ? k : P.N), lck);
       }
       limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
@@ -877,11 +882,7 @@ struct Solver {
     // conic AL expansion at one knot: gradient A'g added to qz, Hessian A' M A added to hh.
     // Row j and column j of the knot's constraint table are loaded here (L2-resident, shared by
     // every instance).
-    auto cone_expand = [&](int k, double z, double lam, double& qz, double (&hh)[NZ]) {
-      ConK ck;
-      double acol[16];
-      con_load(k, ck);
-      con_col(k, acol);
+    auto cone_expand = [&](int k, const ConK& ck, const double (&acol)[16], double z, double lam, double& qz, double (&hh)[NZ]) {
       const bool act = con_act(ck.cm, k);
       const double v = con_value(z, ck.arow, ck.brow);
       const ConeEval e = cone_eval<true>(v, act ? lam : 0.0, mu, ck.cm, act, dmax, so2);
@@ -908,7 +909,11 @@ struct Solver {
           constexpr int C = decltype(c)::value;
           hT[C] = (j == C) ? hz : 0.0;
         });
-        cone_expand(k, is_x ? z : 0.0, ldg(P.Lc, at(k)), qz, hT);
+        ConK ckT;
+        double acolT[16];
+        con_load(k, ckT);
+        con_col(k, acolT);
+        cone_expand(k, ckT, acolT, is_x ? z : 0.0, ldg(P.Lc, at(k)), qz, hT);
         sfor<0, NX>([&](auto c) { Sx[decltype(c)::value] = hT[decltype(c)::value]; });
       } else {
         sfor<0, NX>([&](auto c) {
@@ -926,7 +931,15 @@ struct Solver {
     double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
     double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
     double lcc = 0.0;
-    if constexpr (CONES) lcc = ldg(P.Lc, at(N - 2));
+    // the knot's constraint table (this lane's row and column, 26+ loads from L2) is requested one knot
+    // ahead like the other operands: the conic kernels run one wave per SIMD, nothing else hides it
+    ConK ckc;
+    double acolc[16];
+    if constexpr (CONES) {
+      lcc = ldg(P.Lc, at(N - 2));
+      con_load(N - 2, ckc);
+      con_col(N - 2, acolc);
+    }
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + at(km));
@@ -946,7 +959,11 @@ struct Solver {
         constexpr int C = decltype(c)::value;
         h[C] = (j == C) ? hz : 0.0;
       });
-      if constexpr (CONES) cone_expand(k, (is_x | is_u) ? z : 0.0, lcc, qz, h);
+      if constexpr (CONES) {
+        cone_expand(k, ckc, acolc, (is_x | is_u) ? z : 0.0, lcc, qz, h);
+        con_load(km, ckc);  // consumed: refill for the next knot
+        con_col(km, acolc);
+      }
       Blk<NX, NU>::GtW(h, g, w);
       const double gz = qz + w[NX];  // Qx[j] on x lanes, Qu[a] on u lanes
       // gather Quu (lower triangle) and Qu to every lane
