@@ -746,12 +746,13 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
-@pytest.mark.parametrize("n,m", [(12, 4), (12, 6)])
+@pytest.mark.parametrize("n,m", [(12, 4), (12, 3), (8, 4), (6, 6), (6, 3), (12, 6), (20, 9)])
 def test_option_fuzz_matches_oracle(oracle, n, m):
     """Random solver options on random problems, cold starts far from the reference: iteration caps that end
     solves in MAX_ITERATIONS / MAX_ITERATIONS_OUTER, short line searches (failed searches and the
     regularisation bumps that follow), dual and penalty caps, reset_duals on and off -- every status,
-    count and trace must equal the oracle's, on the 16-lane kernel (12,4) and on the wide kernel (12,6)."""
+    count and trace must equal the oracle's, on every 16-lane instantiation and on the wide kernel
+    ((12,6): m <= 8 class; (20,9): m <= 12 class)."""
     rng = np.random.default_rng(100 + m)
     B, N = 6, 20
     statuses = set()
@@ -778,6 +779,41 @@ def test_option_fuzz_matches_oracle(oracle, n, m):
             statuses.add(so.status)
             check_against_oracle(st, X, U, b, o, so)
     assert len(statuses) >= 3, statuses       # the fuzz reached several termination statuses
+
+
+def test_conic_option_fuzz_matches_oracle(oracle):
+    """Random solver options on short rocket landings (goal equality + three second-order cones): both
+    cone treatments (soc_second_order on / off), iteration caps, short line searches, penalty schedules.
+    Penalties stay below 1e6 so that no iterate sits exactly on a cone boundary (see the horizon-100 test
+    for what happens there)."""
+    rng = np.random.default_rng(77)
+    B = 4
+    statuses = set()
+    for trial in range(6):
+        N = int(rng.choice([11, 21, 31]))
+        rp = P.gen_rocket_problem(N=N, tf=0.25 * (N - 1), Qfk=1e3, Rk=1.0, theta_thrust_max=float(rng.choice([5.0, 10.0])),
+                                  theta_glideslope=45.0)
+        x0 = np.tile(rp.x0, (B, 1)) + rng.standard_normal((B, 6)) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
+        opts = dict(ROCKET_COLD_OPTS)
+        opts.update(cost_tolerance=10.0 ** rng.uniform(-6, -3), constraint_tolerance=10.0 ** rng.uniform(-6, -3),
+                    penalty_initial=10.0 ** rng.uniform(-1, 2), penalty_scaling=float(rng.choice([5.0, 10.0, 50.0])),
+                    penalty_max=10.0 ** rng.uniform(4, 6), iterations=int(rng.choice([15, 60, 400])),
+                    iterations_inner=int(rng.choice([4, 30, 300])), iterations_outer=int(rng.choice([2, 5, 30])),
+                    iterations_linesearch=int(rng.choice([3, 20])), soc_second_order=int(rng.integers(0, 2)))
+        opts["cost_tolerance_intermediate"] = opts["cost_tolerance"] * 10.0
+        sv = altro.ALTROSolver(rocket_gpu_problem(altro, rp, x0), altro.SolverOptions(**opts))
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            o = rocket_oracle(oracle, rp, x0[b], opts)
+            so = o.solve()
+            statuses.add(so.status)
+            check_against_oracle(st, X, U, b, o, so)
+            for ci in range(len(rp.constraints)):
+                lam_o = o.duals(o.con_ids[ci])
+                lam_g = altro.get_duals(sv, ci)[b].reshape(-1)
+                assert np.abs(lam_g - lam_o).max() <= RTOL * max(1.0, np.abs(lam_o).max())
+    assert len(statuses) >= 2, statuses
 
 
 def test_benchmark_script_functions_run():
