@@ -71,3 +71,12 @@ def test_product_package_never_imports_the_oracle():
                 assert not re.search(r"^\s*(import|from)\s+\S*oracle", src, flags=re.M), f
                 assert not re.search(r"#include\s+\S*oracle", src), f
                 assert "oracle_py" not in src and "libaltro_oracle" not in src, f
+
+
+def test_integration_doc_binds_every_export():
+    """INTEGRATION.md's Julia shim names every entry point of include/altro_batch.h."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [s for s in altro._lib.EXPORTS if (":" + s) not in doc]
+    assert not missing, missing
