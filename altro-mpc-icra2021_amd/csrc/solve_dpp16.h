@@ -54,6 +54,13 @@
 #ifndef ALTRO_NA
 #define ALTRO_NA 4           // line-search step sizes evaluated per streaming sweep
 #endif
+#ifndef ALTRO_PRIO_SERIAL
+// Issue priority (s_setprio) of a wave while it is in a phase that is a serial dependency chain with few
+// instructions (rollouts, gradient sweep); the backward pass runs at 0.  When the two waves of a SIMD are
+// in different phases, the chain's next instruction issues as soon as it is ready and the backward pass
+// of the other wave -- hundreds of independent FMAs per knot -- fills every other slot.
+#define ALTRO_PRIO_SERIAL 1  // measured 0..3 on the headline: 1 is +1 %, 2 and 3 about the same, 0 = off
+#endif
 #ifndef ALTRO_SYMMETRIZE
 #define ALTRO_SYMMETRIZE 0   // 1: S <- (S + S')/2 after every knot (as Altro.jl; costs 6 %)
 #endif
@@ -484,6 +491,7 @@ struct Solver {
   //          cur^1 (dead storage for every row that is not iterating, so stores need no mask).
   template <bool OPEN>
   __device__ RollOut rollout(bool take, bool shift) {
+    __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);  // latency-bound phase: see ALTRO_PRIO_SERIAL
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const int cur = rs->cur, kref = rs->kref;
@@ -684,12 +692,14 @@ struct Solver {
     r.limit = row_any(limit, lane);
     r.unchanged = !row_any(changed, lane);
     r.tiny = !row_any(big, lane);
+    __builtin_amdgcn_s_setprio(0);
     return r;
   }
 
   // gradient_todorov!: mean_k max_a |d_k,a| / (|u_k,a| + 1) on the current plane.  Evaluated
   // lazily: the reference only uses it in the convergence test, which also needs dJ < tol.
   __device__ double todorov() {
+    __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
     const unsigned zs = plane(rs->cur);
     const int N = P.N;
     const int ra = is_u ? (j - NX) : 0;
@@ -712,6 +722,7 @@ struct Solver {
         acc += (k0 + Tt < N - 1) ? m : 0.0;
       });
     }
+    __builtin_amdgcn_s_setprio(0);
     return acc / (double)(N - 1);
   }
 
