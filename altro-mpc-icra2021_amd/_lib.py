@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ALTRO_HIP_LIB") or os.path.join(CSRC, "libaltro_hip.s
 
 TRACE_LEN = 16
 
-OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = range(5)
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE, ERR_INTERNAL = range(6)
 CON_BOX, CON_LINEAR, CON_SOC = 0, 1, 2
 SENSE_EQ, SENSE_INEQ = 0, 1
 
@@ -33,6 +33,7 @@ EXPORTS = [
     "altro_batch_get_work_counters", "altro_batch_get_wave_cycles", "altro_batch_get_solve_counters", "altro_mpc_run_async",
     "altro_mpc_set_noise_model", "altro_mpc_set_shift", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
+    "altro_mpc_prepare_async", "altro_batch_benchmark_solve",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -61,7 +62,7 @@ class AltroError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Generate the DPP block include and compile the HIP library for gfx950, in tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "gen_dpp_blocks.py")]
+    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "gen_dpp_blocks.py")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "altro_batch.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -132,6 +133,8 @@ def lib():
     L.altro_mpc_set_noise.argtypes = [H, dp, C.c_int32]
     L.altro_mpc_step_async.argtypes = [H, C.c_int32]
     L.altro_batch_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    L.altro_mpc_prepare_async.argtypes = [H, C.c_int32]
+    L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name != "altro_last_error":
             getattr(L, name).restype = C.c_int32

@@ -261,6 +261,20 @@ def solve(solver):
     return solver
 
 
+def benchmark_solve(solver, samples=10, evals=10):
+    """benchmark_solve!(solver; samples, evals) (random_linear_problem.jl:161 with samples=5, evals=5):
+    the solver's trajectory is saved, then 1 warm-up + samples x evals repetitions of
+    { initial_trajectory!(solver, Z0); solve!(solver) } run on the device.  Duals and penalties are
+    NOT restored between repetitions (Altro.jl restores the primal trajectory only), so with
+    reset_duals=false the statistics left behind -- the ones the reference stores in its *.jld2
+    files -- are those of a solve from converged multipliers.  Returns the per-sample times in ms
+    for the whole batch (BenchmarkTools' trial: time of a sample / evals)."""
+    ms = np.zeros(samples, dtype=np.float32)
+    solver._chk(solver._L.altro_batch_benchmark_solve(solver.h, int(samples), int(evals),
+                                                      ms.ctypes.data_as(C.POINTER(C.c_float))))
+    return ms
+
+
 def states(solver):
     X = np.empty((solver.B, solver.N, solver.n))
     solver._chk(solver._L.altro_batch_get_states(solver.h, _p(X)))

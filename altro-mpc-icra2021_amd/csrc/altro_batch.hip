@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/altro_batch.h"
+#include "launch_ring.h"
 #include "solve_dpp16.h"
 #include "wide_backend.h"
 
@@ -31,8 +32,9 @@ struct altro_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
-  std::vector<hipEvent_t> hist;  // start/end event pairs of solve launches since the last reset
-  size_t hist_used = 0;
+  altro::LaunchRing ring;        // start/end event pairs of the most recent solve launches
+  double* Zsave = nullptr;       // [N][Bp][16]: Z0 of altro_batch_benchmark_solve
+  hipEvent_t bev0 = nullptr, bev1 = nullptr;
   long long *n_backward = nullptr, *n_rollout = nullptr, *wave_cycles = nullptr;
   long long *n_solves = nullptr, *n_iters = nullptr, *n_ok = nullptr, *n_trials = nullptr;
   // problem data (device)
@@ -284,6 +286,20 @@ __global__ void k_cduals(double* __restrict__ host, double* __restrict__ Lc, int
   }
 }
 
+// benchmark_solve!: Z0 = copy(get_trajectory(solver)) and initial_trajectory!(solver, Z0) on the current plane
+__global__ void k_plane_copy(double* __restrict__ Zp, double* __restrict__ Zs, const int* __restrict__ cur, size_t plane,
+                             int Bp, int N, int save) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW;
+  double* z = Zp + (size_t)cur[inst] * plane;
+  const size_t ks = (size_t)Bp * LW;
+  for (int k = 0; k < N; ++k) {
+    if (save) Zs[(size_t)k * ks + t] = z[(size_t)k * ks + t];
+    else z[(size_t)k * ks + t] = Zs[(size_t)k * ks + t];
+  }
+}
+
 __global__ void k_fill(double* p, double v, size_t nelem) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nelem) p[t] = v;
@@ -296,8 +312,9 @@ static bool supported_dims(int n, int m) {
   return (n == 12 && m == 4) || (n == 6 && m == 3) || (n == 6 && m == 6) || (n == 8 && m == 4) || (n == 12 && m == 3);
 }
 
-static int launch_solve(altro_handle* h, int first_step, int nsteps) {
+static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare_only = 0) {
   altro::SolveParams p{};
+  p.prepare_only = prepare_only;
   p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
   p.kref = h->kref;
   p.first_step = first_step; p.nsteps = nsteps;
@@ -344,196 +361,221 @@ static int upload(altro_handle* h, const double* host, size_t count, size_t stag
   return ALTRO_OK;
 }
 
+// Nothing may propagate across the C boundary: every entry point runs its body inside guard(), which
+// turns std::bad_alloc (the std::vector / std::string members of the handle) and anything else into
+// ALTRO_ERR_INTERNAL.
+template <class F>
+static int32_t guard(altro_handle* h, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    try { if (h) h->err = "out of host memory"; else g_create_err = "out of host memory"; } catch (...) {}
+    return ALTRO_ERR_INTERNAL;
+  } catch (const std::exception& e) {
+    try { if (h) h->err = std::string("internal error: ") + e.what(); else g_create_err = e.what(); } catch (...) {}
+    return ALTRO_ERR_INTERNAL;
+  } catch (...) {
+    return ALTRO_ERR_INTERNAL;
+  }
+}
+
 // ------------------------------------------------------------------ C-ABI
 extern "C" {
 
 int32_t altro_default_opts(altro_opts* o) {
-  if (!o) return ALTRO_ERR_INVALID_ARG;
-  o->cost_tolerance = 1e-4;
-  o->cost_tolerance_intermediate = 1e-4;
-  o->gradient_tolerance = 10.0;
-  o->gradient_tolerance_intermediate = 1.0;
-  o->constraint_tolerance = 1e-6;
-  o->penalty_initial = NAN;
-  o->penalty_scaling = NAN;
-  o->penalty_max = 1e8;
-  o->dual_max = 1e8;
-  o->line_search_lower_bound = 1e-8;
-  o->line_search_upper_bound = 10.0;
-  o->max_cost_value = 1e8;
-  o->max_state_value = 1e8;
-  o->max_control_value = 1e8;
-  o->bp_reg_initial = 0.0;
-  o->bp_reg_increase_factor = 1.6;
-  o->bp_reg_max = 1e8;
-  o->bp_reg_min = 1e-8;
-  o->bp_reg_fp = 10.0;
-  o->iterations = 1000;
-  o->iterations_inner = 300;
-  o->iterations_outer = 30;
-  o->iterations_linesearch = 20;
-  o->dJ_counter_limit = 10;
-  o->reset_duals = 1;
-  o->reset_penalties = 1;
-  o->bp_reg = 0;
-  o->soc_second_order = 1;
-  return ALTRO_OK;
+  return guard(nullptr, [&]() -> int32_t {
+    if (!o) return ALTRO_ERR_INVALID_ARG;
+    o->cost_tolerance = 1e-4;
+    o->cost_tolerance_intermediate = 1e-4;
+    o->gradient_tolerance = 10.0;
+    o->gradient_tolerance_intermediate = 1.0;
+    o->constraint_tolerance = 1e-6;
+    o->penalty_initial = NAN;
+    o->penalty_scaling = NAN;
+    o->penalty_max = 1e8;
+    o->dual_max = 1e8;
+    o->line_search_lower_bound = 1e-8;
+    o->line_search_upper_bound = 10.0;
+    o->max_cost_value = 1e8;
+    o->max_state_value = 1e8;
+    o->max_control_value = 1e8;
+    o->bp_reg_initial = 0.0;
+    o->bp_reg_increase_factor = 1.6;
+    o->bp_reg_max = 1e8;
+    o->bp_reg_min = 1e-8;
+    o->bp_reg_fp = 10.0;
+    o->iterations = 1000;
+    o->iterations_inner = 300;
+    o->iterations_outer = 30;
+    o->iterations_linesearch = 20;
+    o->dJ_counter_limit = 10;
+    o->reset_duals = 1;
+    o->reset_penalties = 1;
+    o->bp_reg = 0;
+    o->soc_second_order = 1;
+    return ALTRO_OK;
+  });
 }
 
 const char* altro_last_error(const altro_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32_t device, altro_handle** out) {
-  if (!dims || !out) { g_create_err = "null argument"; return ALTRO_ERR_INVALID_ARG; }
-  *out = nullptr;
-  if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
-  // (n, m) of the 16-lane kernel set run there; everything else up to n <= 64, m <= 32 runs on the
-  // one-wave-per-instance MFMA kernel (ALTRO_FORCE_WIDE=1 sends every size there: used by the tests)
-  const char* fw = getenv("ALTRO_FORCE_WIDE");
-  const bool use_wide = !supported_dims(dims->n, dims->m) || (fw && fw[0] == '1');
-  if (use_wide && !altro_wide::WideBackend::supports(dims->n, dims->m)) {
-    g_create_err = "unsupported (n, m): the wide kernel holds n <= 64, m <= 32";
-    return ALTRO_ERR_UNSUPPORTED;
-  }
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev < 1) {
-    g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
-    return ALTRO_ERR_HIP;
-  }
-  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return ALTRO_ERR_INVALID_ARG; }
-  if (use_wide) {
-    altro_handle* hw = new (std::nothrow) altro_handle();
-    altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
-    if (!hw || !wb) { g_create_err = "out of host memory"; delete hw; delete wb; return ALTRO_ERR_INVALID_ARG; }
-    altro_opts o0;
-    if (opts) o0 = *opts; else altro_default_opts(&o0);
-    hw->d = *dims;
-    hw->o = o0;
-    hw->device = device;
-    const int rc = wb->create(dims, &o0, device);
-    if (rc) {
-      g_create_err = wb->err;
-      wb->destroy();
-      delete wb;
-      delete hw;
-      return rc;
+  return guard(nullptr, [&]() -> int32_t {
+    if (!dims || !out) { g_create_err = "null argument"; return ALTRO_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
+    // (n, m) of the 16-lane kernel set run there; everything else up to n <= 64, m <= 32 runs on the
+    // one-wave-per-instance MFMA kernel (ALTRO_FORCE_WIDE=1 sends every size there: used by the tests)
+    const char* fw = getenv("ALTRO_FORCE_WIDE");
+    const bool use_wide = !supported_dims(dims->n, dims->m) || (fw && fw[0] == '1');
+    if (use_wide && !altro_wide::WideBackend::supports(dims->n, dims->m)) {
+      g_create_err = "unsupported (n, m): the wide kernel holds n <= 64, m <= 32";
+      return ALTRO_ERR_UNSUPPORTED;
     }
-    hw->wide = wb;
-    *out = hw;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+      g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+      return ALTRO_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return ALTRO_ERR_INVALID_ARG; }
+    if (use_wide) {
+      altro_handle* hw = new (std::nothrow) altro_handle();
+      altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
+      if (!hw || !wb) { g_create_err = "out of host memory"; delete hw; delete wb; return ALTRO_ERR_INVALID_ARG; }
+      altro_opts o0;
+      if (opts) o0 = *opts; else altro_default_opts(&o0);
+      hw->d = *dims;
+      hw->o = o0;
+      hw->device = device;
+      const int rc = wb->create(dims, &o0, device);
+      if (rc) {
+        g_create_err = wb->err;
+        wb->destroy();
+        delete wb;
+        delete hw;
+        return rc;
+      }
+      hw->wide = wb;
+      *out = hw;
+      return ALTRO_OK;
+    }
+    altro_handle* h = new (std::nothrow) altro_handle();
+    if (!h) { g_create_err = "out of host memory"; return ALTRO_ERR_INVALID_ARG; }
+    h->d = *dims;
+    if (opts) h->o = *opts; else altro_default_opts(&h->o);
+    h->device = device;
+    h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
+    auto fail = [&](const char* what, hipError_t er) {
+      g_create_err = std::string(what) + ": " + hipGetErrorString(er);
+      altro_batch_destroy(h);
+      return ALTRO_ERR_HIP;
+    };
+  #define CCHK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) return fail(#call, e2); } while (0)
+    CCHK(hipSetDevice(device));
+    CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CCHK(hipEventCreate(&h->ev0));
+    CCHK(hipEventCreate(&h->ev1));
+    CCHK(hipEventCreate(&h->bev0));
+    CCHK(hipEventCreate(&h->bev1));
+    h->ring.reset();
+    const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
+    const size_t row = Bp * LW;
+    // the kernels address every array with 32-bit element offsets
+    if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || N * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
+      g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
+      altro_batch_destroy(h);
+      return ALTRO_ERR_UNSUPPORTED;
+    }
+    CCHK(hipMalloc(&h->Gcol, Bp * n * LW * sizeof(double)));
+    CCHK(hipMalloc(&h->Grow, Bp * LW * LW * sizeof(double)));
+    CCHK(hipMalloc(&h->fvec, row * sizeof(double)));
+    CCHK(hipMalloc(&h->wd, LW * sizeof(double)));
+    CCHK(hipMalloc(&h->wf, LW * sizeof(double)));
+    CCHK(hipMalloc(&h->zmin, LW * sizeof(double)));
+    CCHK(hipMalloc(&h->zmax, LW * sizeof(double)));
+    CCHK(hipMalloc(&h->x0, row * sizeof(double)));
+    // + one trash row at the end of each (stores of rows that sit out a phase land there)
+    CCHK(hipMalloc(&h->Z, (2 * N + 1) * row * sizeof(double)));
+    for (int j = 0; j < LW; ++j) h->bslot_h[j] = -1;
+    h->nbp = 1;
+    CCHK(hipMalloc(&h->Lb, (N + 1) * Bp * 2 * h->nbp * sizeof(double)));
+    CCHK(hipMalloc(&h->bslot, LW * sizeof(int)));
+    CCHK(hipMalloc(&h->Acon, N * LW * LW * sizeof(double)));
+    CCHK(hipMalloc(&h->bcon, N * LW * sizeof(double)));
+    CCHK(hipMalloc(&h->cmeta, N * LW * 4 * sizeof(int)));
+    CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
+    CCHK(hipMalloc(&h->noise_w, LW * sizeof(double)));
+    CCHK(hipMalloc(&h->noise_grp, LW * sizeof(int)));
+    {
+      std::vector<double> w(LW, 0.01);  // 1 % of ||x0||_inf (random_linear_problem.jl:129)
+      std::vector<int> g(LW, 0);
+      CCHK(hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CCHK(hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      CCHK(hipStreamSynchronize(h->stream));
+    }
+    CCHK(hipMalloc(&h->Lc, (N + 1) * row * sizeof(double)));
+    h->Acon_h.assign(N * LW * LW, 0.0);
+    h->bcon_h.assign(N * LW, 0.0);
+    h->cmeta_h.assign(N * LW * 4, 0);
+    for (size_t e = 0; e < N * LW; ++e) h->cmeta_h[4 * e + 2] = -1;
+    CCHK(hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMemsetAsync(h->Lc, 0, (N + 1) * row * sizeof(double), h->stream));
+    CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->KD, N * Bp * m * LW * sizeof(double)));  // N-1 gain blocks + a trash slot
+    CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->status, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->cost, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->cmax, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->Jtrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+    CCHK(hipMalloc(&h->ctrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+    CCHK(hipMalloc(&h->atrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
+    CCHK(hipMemsetAsync(h->atrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
+    CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->wave_cycles, Bp * 2 * sizeof(long long)));
+    CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->n_trials, Bp * sizeof(long long)));
+    CCHK(hipMemsetAsync(h->n_trials, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 2 * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->Lb, 0, (N + 1) * Bp * 2 * h->nbp * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->KD, 0, N * Bp * m * LW * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->iters_outer, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->status, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->cost, 0, Bp * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->cmax, 0, Bp * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->Jtrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->ctrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->x0, 0, row * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->fvec, 0, row * sizeof(double), h->stream));
+    {
+      // no bounds until a BOX constraint is added
+      std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
+      CCHK(hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CCHK(hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CCHK(hipStreamSynchronize(h->stream));
+    }
+    hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->mu, 1.0, (size_t)Bp);
+    CCHK(hipStreamSynchronize(h->stream));
+  #undef CCHK
+    *out = h;
     return ALTRO_OK;
-  }
-  altro_handle* h = new (std::nothrow) altro_handle();
-  if (!h) { g_create_err = "out of host memory"; return ALTRO_ERR_INVALID_ARG; }
-  h->d = *dims;
-  if (opts) h->o = *opts; else altro_default_opts(&h->o);
-  h->device = device;
-  h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
-  auto fail = [&](const char* what, hipError_t er) {
-    g_create_err = std::string(what) + ": " + hipGetErrorString(er);
-    altro_batch_destroy(h);
-    return ALTRO_ERR_HIP;
-  };
-#define CCHK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) return fail(#call, e2); } while (0)
-  CCHK(hipSetDevice(device));
-  CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CCHK(hipEventCreate(&h->ev0));
-  CCHK(hipEventCreate(&h->ev1));
-  const size_t Bp = h->Bp, N = dims->N, n = dims->n, m = dims->m;
-  const size_t row = Bp * LW;
-  // the kernels address every array with 32-bit element offsets
-  if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || N * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
-    g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
-    altro_batch_destroy(h);
-    return ALTRO_ERR_UNSUPPORTED;
-  }
-  CCHK(hipMalloc(&h->Gcol, Bp * n * LW * sizeof(double)));
-  CCHK(hipMalloc(&h->Grow, Bp * LW * LW * sizeof(double)));
-  CCHK(hipMalloc(&h->fvec, row * sizeof(double)));
-  CCHK(hipMalloc(&h->wd, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->wf, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->zmin, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->zmax, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->x0, row * sizeof(double)));
-  // + one trash row at the end of each (stores of rows that sit out a phase land there)
-  CCHK(hipMalloc(&h->Z, (2 * N + 1) * row * sizeof(double)));
-  for (int j = 0; j < LW; ++j) h->bslot_h[j] = -1;
-  h->nbp = 1;
-  CCHK(hipMalloc(&h->Lb, (N + 1) * Bp * 2 * h->nbp * sizeof(double)));
-  CCHK(hipMalloc(&h->bslot, LW * sizeof(int)));
-  CCHK(hipMalloc(&h->Acon, N * LW * LW * sizeof(double)));
-  CCHK(hipMalloc(&h->bcon, N * LW * sizeof(double)));
-  CCHK(hipMalloc(&h->cmeta, N * LW * 4 * sizeof(int)));
-  CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
-  CCHK(hipMalloc(&h->noise_w, LW * sizeof(double)));
-  CCHK(hipMalloc(&h->noise_grp, LW * sizeof(int)));
-  {
-    std::vector<double> w(LW, 0.01);  // 1 % of ||x0||_inf (random_linear_problem.jl:129)
-    std::vector<int> g(LW, 0);
-    CCHK(hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    CCHK(hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    CCHK(hipStreamSynchronize(h->stream));
-  }
-  CCHK(hipMalloc(&h->Lc, (N + 1) * row * sizeof(double)));
-  h->Acon_h.assign(N * LW * LW, 0.0);
-  h->bcon_h.assign(N * LW, 0.0);
-  h->cmeta_h.assign(N * LW * 4, 0);
-  for (size_t e = 0; e < N * LW; ++e) h->cmeta_h[4 * e + 2] = -1;
-  CCHK(hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMemsetAsync(h->Lc, 0, (N + 1) * row * sizeof(double), h->stream));
-  CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
-  CCHK(hipMalloc(&h->KD, N * Bp * m * LW * sizeof(double)));  // N-1 gain blocks + a trash slot
-  CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
-  CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
-  CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
-  CCHK(hipMalloc(&h->status, Bp * sizeof(int)));
-  CCHK(hipMalloc(&h->cost, Bp * sizeof(double)));
-  CCHK(hipMalloc(&h->cmax, Bp * sizeof(double)));
-  CCHK(hipMalloc(&h->Jtrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
-  CCHK(hipMalloc(&h->ctrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
-  CCHK(hipMalloc(&h->atrace, Bp * ALTRO_TRACE_LEN * sizeof(double)));
-  CCHK(hipMemsetAsync(h->atrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
-  CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
-  CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
-  CCHK(hipMalloc(&h->wave_cycles, Bp * 2 * sizeof(long long)));
-  CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
-  CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
-  CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
-  CCHK(hipMalloc(&h->n_trials, Bp * sizeof(long long)));
-  CCHK(hipMemsetAsync(h->n_trials, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 2 * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
-  CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Lb, 0, (N + 1) * Bp * 2 * h->nbp * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->KD, 0, N * Bp * m * LW * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->cur, 0, Bp * sizeof(int), h->stream));
-  CCHK(hipMemsetAsync(h->iters, 0, Bp * sizeof(int), h->stream));
-  CCHK(hipMemsetAsync(h->iters_outer, 0, Bp * sizeof(int), h->stream));
-  CCHK(hipMemsetAsync(h->status, 0, Bp * sizeof(int), h->stream));
-  CCHK(hipMemsetAsync(h->cost, 0, Bp * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->cmax, 0, Bp * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->Jtrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->ctrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->x0, 0, row * sizeof(double), h->stream));
-  CCHK(hipMemsetAsync(h->fvec, 0, row * sizeof(double), h->stream));
-  {
-    // no bounds until a BOX constraint is added
-    std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
-    CCHK(hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    CCHK(hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    CCHK(hipStreamSynchronize(h->stream));
-  }
-  hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->mu, 1.0, (size_t)Bp);
-  CCHK(hipStreamSynchronize(h->stream));
-#undef CCHK
-  *out = h;
-  return ALTRO_OK;
+  });
 }
 
 // release everything the 16-lane backend owns on the device (the handle itself stays)
@@ -546,13 +588,13 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
-                   (void**)&h->n_ok, (void**)&h->n_trials};
+                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
   h->stage_bytes = 0;
-  for (hipEvent_t e : h->hist) hipEventDestroy(e);
-  h->hist.clear();
-  h->hist_used = 0;
+  h->ring.destroy();
+  if (h->bev0) { hipEventDestroy(h->bev0); h->bev0 = nullptr; }
+  if (h->bev1) { hipEventDestroy(h->bev1); h->bev1 = nullptr; }
   if (h->ev0) { hipEventDestroy(h->ev0); h->ev0 = nullptr; }
   if (h->ev1) { hipEventDestroy(h->ev1); h->ev1 = nullptr; }
   if (h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
@@ -573,63 +615,69 @@ int32_t altro_batch_destroy(altro_handle* h) {
 
 int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
                                  int32_t per_knot, int32_t per_instance) {
-  WIDE_FWD(h, set_dynamics(A, B, f, per_knot, per_instance));
-  if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
-  if (per_knot) {
-    // Per-knot (LTV) dynamics exist on the one-wave-per-instance kernel only.  A handle on which nothing
-    // but create has happened moves there; the Julia model is fixed when ALTROSolver(prob, opts) is built
-    // (ALTROParams.jl:61,96), so set_dynamics is the first call of every harness.
-    if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
-      FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
-                                     "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
-    altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
-    if (!wb) FAIL(h, ALTRO_ERR_INVALID_ARG, "out of host memory");
-    free_dpp_backend(h);
-    const int rc = wb->create(&h->d, &h->o, h->device);
-    if (rc) {
-      h->err = wb->err;
-      wb->destroy();
-      delete wb;
-      return rc;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, set_dynamics(A, B, f, per_knot, per_instance));
+    if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
+    if (per_knot) {
+      // Per-knot (LTV) dynamics exist on the one-wave-per-instance kernel only.  A handle on which nothing
+      // but create has happened moves there; the Julia model is fixed when ALTROSolver(prob, opts) is built
+      // (ALTROParams.jl:61,96), so set_dynamics is the first call of every harness.
+      if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
+        FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
+                                       "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
+      altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
+      if (!wb) FAIL(h, ALTRO_ERR_INTERNAL, "out of host memory");
+      // the wide backend is created BEFORE the 16-lane one is released: if it cannot be (e.g. no device
+      // memory for its arrays) the handle stays a working 16-lane handle and only this call fails
+      const int rc = wb->create(&h->d, &h->o, h->device);
+      if (rc) {
+        h->err = wb->err;
+        wb->destroy();
+        delete wb;
+        return rc;
+      }
+      free_dpp_backend(h);
+      h->wide = wb;
+      const int rc2 = wb->set_dynamics(A, B, f, per_knot, per_instance);
+      if (rc2) h->err = wb->err;
+      return rc2;
     }
-    h->wide = wb;
-    const int rc2 = wb->set_dynamics(A, B, f, per_knot, per_instance);
-    if (rc2) h->err = wb->err;
-    return rc2;
-  }
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t n = h->d.n, m = h->d.m;
-  const size_t nb = per_instance ? h->d.batch : 1;
-  const size_t tot = nb * (n * n + n * m + n);
-  int rc = ensure_stage(h, tot * sizeof(double));
-  if (rc) return rc;
-  if ((rc = upload(h, A, nb * n * n, 0))) return rc;
-  if ((rc = upload(h, B, nb * n * m, nb * n * n))) return rc;
-  if (f && (rc = upload(h, f, nb * n, nb * (n * n + n * m)))) return rc;
-  hipLaunchKernelGGL(k_pack_dyn, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage,
-                     h->stage + nb * n * n, f ? h->stage + nb * (n * n + n * m) : nullptr, h->Gcol, h->Grow, h->fvec,
-                     h->d.batch, h->Bp, (int)n, (int)m, per_instance ? 1 : 0);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->have_dyn = true;
-  h->dyn_per_instance = per_instance != 0;
-  return ALTRO_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = h->d.n, m = h->d.m;
+    const size_t nb = per_instance ? h->d.batch : 1;
+    const size_t tot = nb * (n * n + n * m + n);
+    int rc = ensure_stage(h, tot * sizeof(double));
+    if (rc) return rc;
+    if ((rc = upload(h, A, nb * n * n, 0))) return rc;
+    if ((rc = upload(h, B, nb * n * m, nb * n * n))) return rc;
+    if (f && (rc = upload(h, f, nb * n, nb * (n * n + n * m)))) return rc;
+    hipLaunchKernelGGL(k_pack_dyn, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage,
+                       h->stage + nb * n * n, f ? h->stage + nb * (n * n + n * m) : nullptr, h->Gcol, h->Grow, h->fvec,
+                       h->d.batch, h->Bp, (int)n, (int)m, per_instance ? 1 : 0);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_dyn = true;
+    h->dyn_per_instance = per_instance != 0;
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const double* Rd, const double* Qfd, double dt) {
-  WIDE_FWD(h, set_tracking_cost(Qd, Rd, Qfd, dt));
-  if (!h || !Qd || !Rd || !Qfd || !(dt > 0)) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const int n = h->d.n, m = h->d.m;
-  std::vector<double> wd(LW, 0.0), wf(LW, 0.0);
-  for (int j = 0; j < n; ++j) { wd[j] = dt * Qd[j]; wf[j] = Qfd[j]; }
-  for (int j = 0; j < m; ++j) wd[n + j] = dt * Rd[j];
-  HIPCHK(h, hipMemcpyAsync(h->wd, wd.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->wf, wf.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->dt = dt;
-  h->have_cost = true;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, set_tracking_cost(Qd, Rd, Qfd, dt));
+    if (!h || !Qd || !Rd || !Qfd || !(dt > 0)) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int n = h->d.n, m = h->d.m;
+    std::vector<double> wd(LW, 0.0), wf(LW, 0.0);
+    for (int j = 0; j < n; ++j) { wd[j] = dt * Qd[j]; wf[j] = Qfd[j]; }
+    for (int j = 0; j < m; ++j) wd[n + j] = dt * Rd[j];
+    HIPCHK(h, hipMemcpyAsync(h->wd, wd.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->wf, wf.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dt = dt;
+    h->have_cost = true;
+    return ALTRO_OK;
+  });
 }
 
 // Pack the recorded LINEAR / SOC constraints onto the 16 constraint-row lanes and fill the per-knot
@@ -710,106 +758,114 @@ static int pack_constraints(altro_handle* h) {
 int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense, int32_t k_first, int32_t k_last,
                                    int32_t p, const double* A, const double* b, const double* zmin, const double* zmax,
                                    int32_t per_knot, int32_t* con_id) {
-  WIDE_FWD(h, add_constraint(kind, sense, k_first, k_last, p, A, b, zmin, zmax, per_knot, con_id));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  if (k_first < 0 || k_last >= h->d.N || k_last < k_first) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad knot range");
-  HIPCHK(h, hipSetDevice(h->device));
-  const int nz = h->d.n + h->d.m;
-  if (kind == ALTRO_CON_LINEAR || kind == ALTRO_CON_SOC) {
-    if (!A || !b || p < 1) return ALTRO_ERR_INVALID_ARG;
-    if (kind == ALTRO_CON_SOC && (p < 2 || p > 4)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "second-order cones of dimension 2..4 are built");
-    if (kind == ALTRO_CON_LINEAR && sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
-    if (h->con_locked) FAIL(h, ALTRO_ERR_STATE, "constraints must be added before the first solve");
-    altro_handle::ConBlock cb;
-    cb.id = h->ncon; cb.kind = kind; cb.sense = sense; cb.k0 = k_first; cb.k1 = k_last; cb.p = p;
-    cb.per_knot = per_knot ? 1 : 0;
-    const size_t nblk = per_knot ? (size_t)(k_last - k_first + 1) : 1;
-    cb.A.assign(A, A + nblk * p * nz);
-    cb.b.assign(b, b + nblk * p);
-    for (int r = 0; r < LW; ++r) cb.lanes[r] = -1;
-    h->cons.push_back(cb);
-    h->con_dirty = true;
-    int rc = pack_constraints(h);
-    if (rc) { h->cons.pop_back(); h->con_dirty = true; pack_constraints(h); return rc; }
-    if (con_id) *con_id = h->ncon;
-    h->ncon++;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, add_constraint(kind, sense, k_first, k_last, p, A, b, zmin, zmax, per_knot, con_id));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    if (k_first < 0 || k_last >= h->d.N || k_last < k_first) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad knot range");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nz = h->d.n + h->d.m;
+    if (kind == ALTRO_CON_LINEAR || kind == ALTRO_CON_SOC) {
+      if (!A || !b || p < 1) return ALTRO_ERR_INVALID_ARG;
+      if (kind == ALTRO_CON_SOC && (p < 2 || p > 4)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "second-order cones of dimension 2..4 are built");
+      if (kind == ALTRO_CON_LINEAR && sense != ALTRO_SENSE_EQ && sense != ALTRO_SENSE_INEQ) return ALTRO_ERR_INVALID_ARG;
+      if (h->con_locked) FAIL(h, ALTRO_ERR_STATE, "constraints must be added before the first solve");
+      altro_handle::ConBlock cb;
+      cb.id = h->ncon; cb.kind = kind; cb.sense = sense; cb.k0 = k_first; cb.k1 = k_last; cb.p = p;
+      cb.per_knot = per_knot ? 1 : 0;
+      const size_t nblk = per_knot ? (size_t)(k_last - k_first + 1) : 1;
+      cb.A.assign(A, A + nblk * p * nz);
+      cb.b.assign(b, b + nblk * p);
+      for (int r = 0; r < LW; ++r) cb.lanes[r] = -1;
+      h->cons.push_back(cb);
+      h->con_dirty = true;
+      int rc = pack_constraints(h);
+      if (rc) { h->cons.pop_back(); h->con_dirty = true; pack_constraints(h); return rc; }
+      if (con_id) *con_id = h->ncon;
+      h->ncon++;
+      return ALTRO_OK;
+    }
+    if (kind != ALTRO_CON_BOX) return ALTRO_ERR_INVALID_ARG;
+    if (h->box_id >= 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "one BOX constraint per problem");
+    if (!zmin || !zmax) return ALTRO_ERR_INVALID_ARG;
+    std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
+    for (int j = 0; j < nz; ++j) { lo[j] = zmin[j]; hi[j] = zmax[j]; }
+    HIPCHK(h, hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // compact dual rows: one slot per element with at least one finite bound
+    int nb = 0;
+    for (int j = 0; j < LW; ++j) h->bslot_h[j] = (j < nz && (std::isfinite(lo[j]) || std::isfinite(hi[j]))) ? nb++ : -1;
+    h->nbp = nb > 0 ? nb : 1;
+    HIPCHK(h, hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(h->Lb));
+    h->Lb = nullptr;
+    {
+      const size_t lbytes = (size_t)(h->d.N + 1) * h->Bp * 2 * h->nbp * sizeof(double);
+      HIPCHK(h, hipMalloc(&h->Lb, lbytes));
+      HIPCHK(h, hipMemsetAsync(h->Lb, 0, lbytes, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->box_k0 = k_first;
+    h->box_k1 = k_last;
+    h->box_id = h->ncon++;
+    if (con_id) *con_id = h->box_id;
     return ALTRO_OK;
-  }
-  if (kind != ALTRO_CON_BOX) return ALTRO_ERR_INVALID_ARG;
-  if (h->box_id >= 0) FAIL(h, ALTRO_ERR_UNSUPPORTED, "one BOX constraint per problem");
-  if (!zmin || !zmax) return ALTRO_ERR_INVALID_ARG;
-  std::vector<double> lo(LW, -INFINITY), hi(LW, INFINITY);
-  for (int j = 0; j < nz; ++j) { lo[j] = zmin[j]; hi[j] = zmax[j]; }
-  HIPCHK(h, hipMemcpyAsync(h->zmin, lo.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->zmax, hi.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  // compact dual rows: one slot per element with at least one finite bound
-  int nb = 0;
-  for (int j = 0; j < LW; ++j) h->bslot_h[j] = (j < nz && (std::isfinite(lo[j]) || std::isfinite(hi[j]))) ? nb++ : -1;
-  h->nbp = nb > 0 ? nb : 1;
-  HIPCHK(h, hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipFree(h->Lb));
-  h->Lb = nullptr;
-  {
-    const size_t lbytes = (size_t)(h->d.N + 1) * h->Bp * 2 * h->nbp * sizeof(double);
-    HIPCHK(h, hipMalloc(&h->Lb, lbytes));
-    HIPCHK(h, hipMemsetAsync(h->Lb, 0, lbytes, h->stream));
-  }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->box_k0 = k_first;
-  h->box_k1 = k_last;
-  h->box_id = h->ncon++;
-  if (con_id) *con_id = h->box_id;
-  return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A, const double* b) {
-  WIDE_FWD(h, update_constraint_data(con_id, A, b));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const int nz = h->d.n + h->d.m;
-  for (auto& cb : h->cons) {
-    if (cb.id != con_id) continue;
-    const size_t nblk = cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1;
-    if (A) cb.A.assign(A, A + nblk * cb.p * nz);
-    if (b) cb.b.assign(b, b + nblk * cb.p);
-    // same lanes, new coefficients: refresh the tables (the solver sees it at the next solve, as
-    // the reference's in-place mutation does: grasp_mpc_helpers.jl:46-55)
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->con_dirty = true;
-    return pack_constraints(h);
-  }
-  FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown or non-affine constraint id");
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, update_constraint_data(con_id, A, b));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nz = h->d.n + h->d.m;
+    for (auto& cb : h->cons) {
+      if (cb.id != con_id) continue;
+      const size_t nblk = cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1;
+      if (A) cb.A.assign(A, A + nblk * cb.p * nz);
+      if (b) cb.b.assign(b, b + nblk * cb.p);
+      // same lanes, new coefficients: refresh the tables (the solver sees it at the next solve, as
+      // the reference's in-place mutation does: grasp_mpc_helpers.jl:46-55)
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      h->con_dirty = true;
+      return pack_constraints(h);
+    }
+    FAIL(h, ALTRO_ERR_INVALID_ARG, "unknown or non-affine constraint id");
+  });
 }
 
 int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
-  WIDE_FWD(h, set_initial_state(x0));
-  if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t cnt = (size_t)h->d.batch * h->d.n;
-  int rc = ensure_stage(h, cnt * sizeof(double));
-  if (rc) return rc;
-  if ((rc = upload(h, x0, cnt))) return rc;
-  hipLaunchKernelGGL(k_pack_x0, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->x0, h->d.batch,
-                     h->Bp, h->d.n);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, set_initial_state(x0));
+    if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->d.batch * h->d.n;
+    int rc = ensure_stage(h, cnt * sizeof(double));
+    if (rc) return rc;
+    if ((rc = upload(h, x0, cnt))) return rc;
+    hipLaunchKernelGGL(k_pack_x0, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->x0, h->d.batch,
+                       h->Bp, h->d.n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_initial_state(altro_handle* h, double* x0) {
-  WIDE_FWD(h, get_initial_state(x0));
-  if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t cnt = (size_t)h->d.batch * h->d.n;
-  int rc = ensure_stage(h, cnt * sizeof(double));
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_unpack_x0, grid_for((size_t)h->d.batch * LW), dim3(256), 0, h->stream, h->stage, h->x0,
-                     h->d.batch, h->d.n);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(x0, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_initial_state(x0));
+    if (!h || !x0) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->d.batch * h->d.n;
+    int rc = ensure_stage(h, cnt * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_x0, grid_for((size_t)h->d.batch * LW), dim3(256), 0, h->stream, h->stage, h->x0,
+                       h->d.batch, h->d.n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(x0, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 static int set_ref_common(altro_handle* h, const double* Xref, const double* Uref, int Nt) {
@@ -836,47 +892,55 @@ static int set_ref_common(altro_handle* h, const double* Xref, const double* Ure
 }
 
 int32_t altro_batch_set_reference(altro_handle* h, const double* Xref, const double* Uref) {
-  WIDE_FWD(h, set_reference(Xref, Uref));
-  if (!h || !Xref || !Uref) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  return set_ref_common(h, Xref, Uref, h->d.N);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, set_reference(Xref, Uref));
+    if (!h || !Xref || !Uref) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    return set_ref_common(h, Xref, Uref, h->d.N);
+  });
 }
 
 int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, const double* U) {
-  WIDE_FWD(h, set_initial_trajectory(X, U));
-  if (!h || !U) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t B = h->d.batch, N = h->d.N, n = h->d.n, m = h->d.m;
-  const size_t cx = X ? B * N * n : 0, cu = B * (N - 1) * m;
-  int rc = ensure_stage(h, (cx + cu) * sizeof(double));
-  if (rc) return rc;
-  if (X && (rc = upload(h, X, cx, 0))) return rc;
-  if ((rc = upload(h, U, cu, cx))) return rc;
-  const size_t plane = N * (size_t)h->Bp * LW;
-  hipLaunchKernelGGL(k_pack_traj, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->stage + cx, h->Z,
-                     h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m, 1, X ? 1 : 0);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, set_initial_trajectory(X, U));
+    if (!h || !U) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t B = h->d.batch, N = h->d.N, n = h->d.n, m = h->d.m;
+    const size_t cx = X ? B * N * n : 0, cu = B * (N - 1) * m;
+    int rc = ensure_stage(h, (cx + cu) * sizeof(double));
+    if (rc) return rc;
+    if (X && (rc = upload(h, X, cx, 0))) return rc;
+    if ((rc = upload(h, U, cu, cx))) return rc;
+    const size_t plane = N * (size_t)h->Bp * LW;
+    hipLaunchKernelGGL(k_pack_traj, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->stage + cx, h->Z,
+                       h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m, 1, X ? 1 : 0);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
-  WIDE_FWD(h, shift_fill(primal, dual));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t plane = (size_t)h->d.N * h->Bp * LW;
-  hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lb,
-                     h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0, h->Lc,
-                     h->cmeta, h->ncrows);
-  HIPCHK(h, hipGetLastError());
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, shift_fill(primal, dual));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t plane = (size_t)h->d.N * h->Bp * LW;
+    hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lb,
+                       h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0, h->Lc,
+                       h->cmeta, h->ncrows);
+    HIPCHK(h, hipGetLastError());
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
-  if (h && h->wide && o) { h->wide->o = *o; h->o = *o; return ALTRO_OK; }
-  if (!h || !o) return ALTRO_ERR_INVALID_ARG;
-  h->o = *o;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide && o) { h->wide->o = *o; h->o = *o; return ALTRO_OK; }
+    if (!h || !o) return ALTRO_ERR_INVALID_ARG;
+    h->o = *o;
+    return ALTRO_OK;
+  });
 }
 
 static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
@@ -887,19 +951,13 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   h->con_locked = true;
   const int last_kref = nsteps > 0 ? first_step + nsteps : h->kref;
   if (last_kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
+  hipEvent_t h0, h1;
+  HIPCHK(h, h->ring.next(&h0, &h1));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  if (h->hist_used + 2 > h->hist.size()) {
-    for (int i = 0; i < 2; ++i) {
-      hipEvent_t e;
-      HIPCHK(h, hipEventCreate(&e));
-      h->hist.push_back(e);
-    }
-  }
-  HIPCHK(h, hipEventRecord(h->hist[h->hist_used], h->stream));
+  HIPCHK(h, hipEventRecord(h0, h->stream));
   rc = launch_solve(h, first_step, nsteps);
   if (rc) return rc;
-  HIPCHK(h, hipEventRecord(h->hist[h->hist_used + 1], h->stream));
-  h->hist_used += 2;
+  HIPCHK(h, hipEventRecord(h1, h->stream));
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
   if (nsteps > 0) h->kref = first_step + nsteps;
@@ -907,23 +965,29 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
 }
 
 int32_t altro_batch_solve_async(altro_handle* h) {
-  WIDE_FWD(h, enqueue(0, 0, 0));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  return enqueue_solve(h, 0, 0);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, enqueue(0, 0, 0));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    return enqueue_solve(h, 0, 0);
+  });
 }
 
 int32_t altro_batch_synchronize(altro_handle* h) {
-  WIDE_FWD(h, synchronize());
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, synchronize());
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_solve(altro_handle* h) {
-  int rc = altro_batch_solve_async(h);
-  if (rc) return rc;
-  return altro_batch_synchronize(h);
+  return guard(h, [&]() -> int32_t {
+    int rc = altro_batch_solve_async(h);
+    if (rc) return rc;
+    return altro_batch_synchronize(h);
+  });
 }
 
 static int get_traj(altro_handle* h, double* X, double* U) {
@@ -943,15 +1007,19 @@ static int get_traj(altro_handle* h, double* X, double* U) {
 }
 
 int32_t altro_batch_get_states(altro_handle* h, double* X) {
-  WIDE_FWD(h, get_planes(X, nullptr));
-  if (!h || !X) return ALTRO_ERR_INVALID_ARG;
-  return get_traj(h, X, nullptr);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_planes(X, nullptr));
+    if (!h || !X) return ALTRO_ERR_INVALID_ARG;
+    return get_traj(h, X, nullptr);
+  });
 }
 
 int32_t altro_batch_get_controls(altro_handle* h, double* U) {
-  WIDE_FWD(h, get_planes(nullptr, U));
-  if (!h || !U) return ALTRO_ERR_INVALID_ARG;
-  return get_traj(h, nullptr, U);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_planes(nullptr, U));
+    if (!h || !U) return ALTRO_ERR_INVALID_ARG;
+    return get_traj(h, nullptr, U);
+  });
 }
 
 static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_host) {
@@ -987,216 +1055,298 @@ static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_ho
 }
 
 int32_t altro_batch_get_duals(altro_handle* h, int32_t con_id, double* lambda) {
-  WIDE_FWD(h, duals(con_id, lambda, false));
-  if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
-  return duals_xfer(h, con_id, lambda, 1);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, duals(con_id, lambda, false));
+    if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
+    return duals_xfer(h, con_id, lambda, 1);
+  });
 }
 
 int32_t altro_batch_set_duals(altro_handle* h, int32_t con_id, const double* lambda) {
-  WIDE_FWD(h, duals(con_id, const_cast<double*>(lambda), true));
-  if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
-  return duals_xfer(h, con_id, const_cast<double*>(lambda), 0);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, duals(con_id, const_cast<double*>(lambda), true));
+    if (!h || !lambda) return ALTRO_ERR_INVALID_ARG;
+    return duals_xfer(h, con_id, const_cast<double*>(lambda), 0);
+  });
 }
 
 int32_t altro_batch_get_stats(altro_handle* h, int32_t* iterations, int32_t* iterations_outer, int32_t* status,
                               double* cost, double* c_max, double* cost_trace, double* cmax_trace) {
-  WIDE_FWD(h, get_stats(iterations, iterations_outer, status, cost, c_max, cost_trace, cmax_trace));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t B = h->d.batch;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (iterations) HIPCHK(h, hipMemcpy(iterations, h->iters, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (iterations_outer) HIPCHK(h, hipMemcpy(iterations_outer, h->iters_outer, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (status) HIPCHK(h, hipMemcpy(status, h->status, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (cost) HIPCHK(h, hipMemcpy(cost, h->cost, B * sizeof(double), hipMemcpyDeviceToHost));
-  if (c_max) HIPCHK(h, hipMemcpy(c_max, h->cmax, B * sizeof(double), hipMemcpyDeviceToHost));
-  if (cost_trace) HIPCHK(h, hipMemcpy(cost_trace, h->Jtrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
-  if (cmax_trace) HIPCHK(h, hipMemcpy(cmax_trace, h->ctrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_stats(iterations, iterations_outer, status, cost, c_max, cost_trace, cmax_trace));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t B = h->d.batch;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (iterations) HIPCHK(h, hipMemcpy(iterations, h->iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (iterations_outer) HIPCHK(h, hipMemcpy(iterations_outer, h->iters_outer, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->status, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (cost) HIPCHK(h, hipMemcpy(cost, h->cost, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (c_max) HIPCHK(h, hipMemcpy(c_max, h->cmax, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (cost_trace) HIPCHK(h, hipMemcpy(cost_trace, h->Jtrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    if (cmax_trace) HIPCHK(h, hipMemcpy(cmax_trace, h->ctrace, B * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_alpha_trace(altro_handle* h, double* alpha_trace) {
-  WIDE_FWD(h, get_alpha_trace(alpha_trace));
-  if (!h || !alpha_trace) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(alpha_trace, h->atrace, (size_t)h->d.batch * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_alpha_trace(alpha_trace));
+    if (!h || !alpha_trace) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(alpha_trace, h->atrace, (size_t)h->d.batch * ALTRO_TRACE_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
-  WIDE_FWD(h, get_gains(K, d));
-  if (!h || (!K && !d)) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const size_t n = h->d.n, m = h->d.m, N = h->d.N, B = h->d.batch, Bp = h->Bp;
-  std::vector<double> kd((N - 1) * Bp * m * LW);
-  HIPCHK(h, hipMemcpy(kd.data(), h->KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost));
-  // device layout [k][instance][control a][lane]: state lane j holds K[a][j], control lane n+a holds d[a]
-  for (size_t b = 0; b < B; ++b)
-    for (size_t k = 0; k + 1 < N; ++k)
-      for (size_t a = 0; a < m; ++a) {
-        const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
-        if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
-        if (d) d[(b * (N - 1) + k) * m + a] = row[n + a];
-      }
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, get_gains(K, d));
+    if (!h || (!K && !d)) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t n = h->d.n, m = h->d.m, N = h->d.N, B = h->d.batch, Bp = h->Bp;
+    std::vector<double> kd((N - 1) * Bp * m * LW);
+    HIPCHK(h, hipMemcpy(kd.data(), h->KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // device layout [k][instance][control a][lane]: state lane j holds K[a][j], control lane n+a holds d[a]
+    for (size_t b = 0; b < B; ++b)
+      for (size_t k = 0; k + 1 < N; ++k)
+        for (size_t a = 0; a < m; ++a) {
+          const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
+          if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
+          if (d) d[(b * (N - 1) + k) * m + a] = row[n + a];
+        }
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms) {
-  WIDE_FWD(h, last_solve_ms(ms));
-  if (!h || !ms) return ALTRO_ERR_INVALID_ARG;
-  if (!h->timed) FAIL(h, ALTRO_ERR_STATE, "no solve has been launched");
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipEventSynchronize(h->ev1));
-  HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, last_solve_ms(ms));
+    if (!h || !ms) return ALTRO_ERR_INVALID_ARG;
+    if (!h->timed) FAIL(h, ALTRO_ERR_STATE, "no solve has been launched");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_timing_reset(altro_handle* h) {
-  WIDE_FWD(h, timing_reset());
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->hist_used = 0;
-  HIPCHK(h, hipMemsetAsync(h->n_backward, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->n_rollout, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->n_solves, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->n_iters, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->n_ok, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->n_trials, 0, h->Bp * sizeof(long long), h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, timing_reset());
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->ring.reset();
+    HIPCHK(h, hipMemsetAsync(h->n_backward, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_rollout, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_solves, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_iters, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_ok, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_trials, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count) {
-  WIDE_FWD(h, timing_get(ms, capacity, count));
-  if (!h || !count) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const int32_t n = (int32_t)(h->hist_used / 2);
-  *count = n;
-  for (int32_t i = 0; ms && i < n && i < capacity; ++i)
-    HIPCHK(h, hipEventElapsedTime(&ms[i], h->hist[2 * i], h->hist[2 * i + 1]));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, timing_get(ms, capacity, count));
+    if (!h || !count) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int32_t n = (int32_t)h->ring.readable();
+    *count = n;
+    for (int32_t i = 0; ms && i < n && i < capacity; ++i) HIPCHK(h, h->ring.elapsed((size_t)i, &ms[i]));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded) {
-  if (h && h->wide) { long long* const src[3] = {h->wide->n_solves, h->wide->n_iters, h->wide->n_ok}; const int rc_ = h->wide->counters(src, solves, iterations, succeeded); if (rc_) h->err = h->wide->err; return rc_; }
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const size_t B = h->d.batch;
-  if (solves) HIPCHK(h, hipMemcpy(solves, h->n_solves, B * sizeof(long long), hipMemcpyDeviceToHost));
-  if (iterations) HIPCHK(h, hipMemcpy(iterations, h->n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
-  if (succeeded) HIPCHK(h, hipMemcpy(succeeded, h->n_ok, B * sizeof(long long), hipMemcpyDeviceToHost));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide) { long long* const src[3] = {h->wide->n_solves, h->wide->n_iters, h->wide->n_ok}; const int rc_ = h->wide->counters(src, solves, iterations, succeeded); if (rc_) h->err = h->wide->err; return rc_; }
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t B = h->d.batch;
+    if (solves) HIPCHK(h, hipMemcpy(solves, h->n_solves, B * sizeof(long long), hipMemcpyDeviceToHost));
+    if (iterations) HIPCHK(h, hipMemcpy(iterations, h->n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
+    if (succeeded) HIPCHK(h, hipMemcpy(succeeded, h->n_ok, B * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes, int64_t* rollouts, int64_t* trials) {
-  if (h && h->wide) { long long* const src[3] = {h->wide->n_backward, h->wide->n_rollout, h->wide->n_trials}; const int rc_ = h->wide->counters(src, backward_passes, rollouts, trials); if (rc_) h->err = h->wide->err; return rc_; }
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const size_t B = h->d.batch;
-  if (backward_passes) HIPCHK(h, hipMemcpy(backward_passes, h->n_backward, B * sizeof(long long), hipMemcpyDeviceToHost));
-  if (rollouts) HIPCHK(h, hipMemcpy(rollouts, h->n_rollout, B * sizeof(long long), hipMemcpyDeviceToHost));
-  if (trials) HIPCHK(h, hipMemcpy(trials, h->n_trials, B * sizeof(long long), hipMemcpyDeviceToHost));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide) { long long* const src[3] = {h->wide->n_backward, h->wide->n_rollout, h->wide->n_trials}; const int rc_ = h->wide->counters(src, backward_passes, rollouts, trials); if (rc_) h->err = h->wide->err; return rc_; }
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t B = h->d.batch;
+    if (backward_passes) HIPCHK(h, hipMemcpy(backward_passes, h->n_backward, B * sizeof(long long), hipMemcpyDeviceToHost));
+    if (rollouts) HIPCHK(h, hipMemcpy(rollouts, h->n_rollout, B * sizeof(long long), hipMemcpyDeviceToHost));
+    if (trials) HIPCHK(h, hipMemcpy(trials, h->n_trials, B * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t capacity, int32_t* count) {
-  if (h && h->wide) { if (count) *count = 0; return ALTRO_OK; }
-  if (!h || !count) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const int32_t n = h->Bp / IPW * 8;
-  *count = n;
-  if (cycles) HIPCHK(h, hipMemcpy(cycles, h->wave_cycles, (size_t)(n < capacity ? n : capacity) * sizeof(long long), hipMemcpyDeviceToHost));
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide) { if (count) *count = 0; return ALTRO_OK; }
+    if (!h || !count) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int32_t n = h->Bp / IPW * 8;
+    *count = n;
+    if (cycles) HIPCHK(h, hipMemcpy(cycles, h->wave_cycles, (size_t)(n < capacity ? n : capacity) * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double* Utrack, int32_t Nt) {
-  WIDE_FWD(h, mpc_set_track(Xtrack, Utrack, Nt));
-  if (!h || !Xtrack || !Utrack) return ALTRO_ERR_INVALID_ARG;
-  if (Nt < h->d.N) FAIL(h, ALTRO_ERR_INVALID_ARG, "track shorter than the horizon");
-  HIPCHK(h, hipSetDevice(h->device));
-  int rc = set_ref_common(h, Xtrack, Utrack, Nt);
-  if (rc) return rc;
-  // initial_trajectory!(prob, Z): the first window of the track (mpc.jl:19-20,45)
-  const size_t row = (size_t)h->Bp * LW;
-  HIPCHK(h, hipMemsetAsync(h->cur, 0, h->Bp * sizeof(int), h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->Z, h->Zref, (size_t)h->d.N * row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->x0, h->Zref, row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  // x0 lanes >= n must be zero: u lanes of Zref knot 0 hold u_0, clear them through the pack path
-  {
-    const size_t cnt = (size_t)h->d.batch * h->d.n;
-    std::vector<double> x0(cnt);
-    const size_t n = h->d.n;
-    for (size_t b = 0; b < (size_t)h->d.batch; ++b)
-      for (size_t j = 0; j < n; ++j) x0[b * n + j] = Xtrack[(b * Nt + 0) * n + j];
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    rc = altro_batch_set_initial_state(h, x0.data());
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, mpc_set_track(Xtrack, Utrack, Nt));
+    if (!h || !Xtrack || !Utrack) return ALTRO_ERR_INVALID_ARG;
+    if (Nt < h->d.N) FAIL(h, ALTRO_ERR_INVALID_ARG, "track shorter than the horizon");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = set_ref_common(h, Xtrack, Utrack, Nt);
     if (rc) return rc;
-  }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return ALTRO_OK;
+    // initial_trajectory!(prob, Z): the first window of the track (mpc.jl:19-20,45)
+    const size_t row = (size_t)h->Bp * LW;
+    HIPCHK(h, hipMemsetAsync(h->cur, 0, h->Bp * sizeof(int), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->Z, h->Zref, (size_t)h->d.N * row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->x0, h->Zref, row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // x0 lanes >= n must be zero: u lanes of Zref knot 0 hold u_0, clear them through the pack path
+    {
+      const size_t cnt = (size_t)h->d.batch * h->d.n;
+      std::vector<double> x0(cnt);
+      const size_t n = h->d.n;
+      for (size_t b = 0; b < (size_t)h->d.batch; ++b)
+        for (size_t j = 0; j < n; ++j) x0[b * n + j] = Xtrack[(b * Nt + 0) * n + j];
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      rc = altro_batch_set_initial_state(h, x0.data());
+      if (rc) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_mpc_set_noise(altro_handle* h, const double* noise, int32_t steps) {
-  WIDE_FWD(h, mpc_set_noise(noise, steps));
-  if (!h || !noise || steps < 1) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  if (h->noise) HIPCHK(h, hipFree(h->noise));
-  h->noise = nullptr;
-  const size_t cnt = (size_t)steps * h->d.batch * h->d.n;
-  HIPCHK(h, hipMalloc(&h->noise, cnt * sizeof(double)));
-  HIPCHK(h, hipMemcpy(h->noise, noise, cnt * sizeof(double), hipMemcpyHostToDevice));
-  h->noise_steps = steps;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, mpc_set_noise(noise, steps));
+    if (!h || !noise || steps < 1) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->noise) HIPCHK(h, hipFree(h->noise));
+    h->noise = nullptr;
+    const size_t cnt = (size_t)steps * h->d.batch * h->d.n;
+    HIPCHK(h, hipMalloc(&h->noise, cnt * sizeof(double)));
+    HIPCHK(h, hipMemcpy(h->noise, noise, cnt * sizeof(double), hipMemcpyHostToDevice));
+    h->noise_steps = steps;
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* weights, const int32_t* groups) {
-  WIDE_FWD(h, mpc_set_noise_model(mode, weights, groups));
-  if (!h || !weights || mode < 0 || mode > 2) return ALTRO_ERR_INVALID_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<double> w(LW, 0.0);
-  std::vector<int> g(LW, 0);
-  for (int i = 0; i < h->d.n; ++i) {
-    w[i] = weights[i];
-    g[i] = groups ? groups[i] : 0;
-    if (g[i] != 0 && g[i] != 1) FAIL(h, ALTRO_ERR_INVALID_ARG, "noise groups are 0 or 1");
-  }
-  HIPCHK(h, hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->noise_mode = mode;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, mpc_set_noise_model(mode, weights, groups));
+    if (!h || !weights || mode < 0 || mode > 2) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<double> w(LW, 0.0);
+    std::vector<int> g(LW, 0);
+    for (int i = 0; i < h->d.n; ++i) {
+      w[i] = weights[i];
+      g[i] = groups ? groups[i] : 0;
+      if (g[i] != 0 && g[i] != 1) FAIL(h, ALTRO_ERR_INVALID_ARG, "noise groups are 0 or 1");
+    }
+    HIPCHK(h, hipMemcpyAsync(h->noise_w, w.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->noise_grp, g.data(), LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->noise_mode = mode;
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift) {
-  if (h && h->wide) { h->wide->mpc_shift = shift ? 1 : 0; return ALTRO_OK; }
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  h->mpc_shift = shift ? 1 : 0;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide) { h->wide->mpc_shift = shift ? 1 : 0; return ALTRO_OK; }
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    h->mpc_shift = shift ? 1 : 0;
+    return ALTRO_OK;
+  });
 }
 
 int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps) {
-  WIDE_FWD(h, mpc_run(first_step, nsteps));
-  if (!h) return ALTRO_ERR_INVALID_ARG;
-  if (nsteps < 1 || first_step < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad step range");
-  if (h->noise && first_step + nsteps > h->noise_steps) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps outside the uploaded noise");
-  if (first_step + nsteps + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps run past the end of the track");
-  return enqueue_solve(h, first_step, nsteps);
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, mpc_run(first_step, nsteps));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    if (nsteps < 1 || first_step < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad step range");
+    if (h->noise && first_step + nsteps > h->noise_steps) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps outside the uploaded noise");
+    if (first_step + nsteps + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "steps run past the end of the track");
+    return enqueue_solve(h, first_step, nsteps);
+  });
 }
 
 int32_t altro_mpc_step_async(altro_handle* h, int32_t step) { return altro_mpc_run_async(h, step, 1); }
 
+int32_t altro_mpc_prepare_async(altro_handle* h, int32_t step) {
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, mpc_prepare(step));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    if (step < 0) FAIL(h, ALTRO_ERR_INVALID_ARG, "bad step");
+    if (h->noise && step + 1 > h->noise_steps) FAIL(h, ALTRO_ERR_INVALID_ARG, "step outside the uploaded noise");
+    if (step + 1 + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_INVALID_ARG, "step runs past the end of the track");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((rc = launch_solve(h, step, 1, 1))) return rc;  // the solve kernel's own plant step, nothing else
+    h->kref = step + 1;
+    return ALTRO_OK;
+  });
+}
+
+int32_t altro_batch_benchmark_solve(altro_handle* h, int32_t samples, int32_t evals, float* sample_ms) {
+  return guard(h, [&]() -> int32_t {
+    WIDE_FWD(h, benchmark_solve(samples, evals, sample_ms));
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    if (samples < 1 || evals < 1) FAIL(h, ALTRO_ERR_INVALID_ARG, "samples and evals must be positive");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t plane = (size_t)h->d.N * h->Bp * LW;
+    if (!h->Zsave) HIPCHK(h, hipMalloc(&h->Zsave, plane * sizeof(double)));
+    const dim3 grid = grid_for((size_t)h->Bp * LW);
+    // Z0 = deepcopy(get_trajectory(solver))
+    hipLaunchKernelGGL(k_plane_copy, grid, dim3(256), 0, h->stream, h->Z, h->Zsave, h->cur, plane, h->Bp, h->d.N, 1);
+    HIPCHK(h, hipGetLastError());
+    auto one = [&]() -> int {  // initial_trajectory!(solver, Z0); solve!(solver)
+      hipLaunchKernelGGL(k_plane_copy, grid, dim3(256), 0, h->stream, h->Z, h->Zsave, h->cur, plane, h->Bp, h->d.N, 0);
+      return enqueue_solve(h, 0, 0);
+    };
+    int rc = one();  // BenchmarkTools' warm-up evaluation
+    if (rc) return rc;
+    for (int32_t s = 0; s < samples; ++s) {
+      HIPCHK(h, hipEventRecord(h->bev0, h->stream));
+      for (int32_t e = 0; e < evals; ++e)
+        if ((rc = one())) return rc;
+      HIPCHK(h, hipEventRecord(h->bev1, h->stream));
+      HIPCHK(h, hipEventSynchronize(h->bev1));
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->bev0, h->bev1));
+      if (sample_ms) sample_ms[s] = ms / (float)evals;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ALTRO_OK;
+  });
+}
+
 int32_t altro_batch_get_stream(altro_handle* h, void** stream) {
-  if (h && h->wide && stream) { *stream = (void*)h->wide->stream; return ALTRO_OK; }
-  if (!h || !stream) return ALTRO_ERR_INVALID_ARG;
-  *stream = (void*)h->stream;
-  return ALTRO_OK;
+  return guard(h, [&]() -> int32_t {
+    if (h && h->wide && stream) { *stream = (void*)h->wide->stream; return ALTRO_OK; }
+    if (!h || !stream) return ALTRO_ERR_INVALID_ARG;
+    *stream = (void*)h->stream;
+    return ALTRO_OK;
+  });
 }
 
 }  // extern "C"

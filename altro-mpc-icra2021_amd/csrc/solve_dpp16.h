@@ -81,6 +81,7 @@ struct SolveParams {
   int box_k0, box_k1;    // knot range of the BOX constraint (box_k1 < box_k0: none)
   int first_step;        // MPC mode: first step index
   int nsteps;            // MPC mode: steps to run in this launch; 0 = plain solve!()
+  int prepare_only;      // MPC mode: plant step + new x0 only (altro_mpc_prepare_async): no shift, no solve
   const double* Gcol;    // [Bp][NX][16]   Gcol[b][k][j] = [A B][k][j]
   const double* Grow;    // [Bp][16][16]   Grow[b][c][i] = [A B][i][c]
   const double* fvec;    // [Bp][16]       affine term (x lanes)
@@ -1190,7 +1191,7 @@ struct Solver {
           const int stp = rs->step;
           const bool go = begin && (stp < (mpc ? nsteps : 1));
           if (mpc && wave_any(go)) plant_step(go, first_step + stp);
-          if (o.reset_duals && wave_any(go)) {  // initialize!: lambda <- 0
+          if (o.reset_duals && !P.prepare_only && wave_any(go)) {  // initialize!: lambda <- 0
             for (int k = P.box_k0; k <= P.box_k1; ++k) {
               stg(P.Lb, lb_at((go & bounded) ? k : P.N, 0), 0.0);
               stg(P.Lb, lb_at((go & bounded) ? k : P.N, 1), 0.0);
@@ -1200,7 +1201,7 @@ struct Solver {
             }
           }
           if (begin) {
-            if (go) {
+            if (go && !P.prepare_only) {
               if (mpc) rs->kref = first_step + stp + 1;  // update_trajectory!(obj, Z_track, k_mpc)
               if (o.reset_penalties) rs->mu = mu0;
               rs->status = ALTRO_UNSOLVED;
@@ -1464,7 +1465,7 @@ struct Solver {
   }
 
   __device__ void finish() {
-    if (j == 0) {
+    if (j == 0 && !P.prepare_only) {  // a prepare-only launch leaves the statistics of the last solve alone
       P.iters[inst] = rs->iters;
       P.iters_outer[inst] = rs->iters_outer;
       P.status[inst] = rs->status;

@@ -1296,6 +1296,7 @@ struct Solver {
       if (mpc) {
         plant_step(first_step + s);
         kref = first_step + s + 1;  // update_trajectory!(obj, Z_track, k_mpc)
+        if (mpc == 2) break;        // altro_mpc_prepare_async: new x0 only, no shift, no solve
         if (P.mpc_shift) shift(true, true);
       }
       solve_one();

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/altro_batch.h"
+#include "launch_ring.h"
 #include "solve_wide.h"
 
 namespace altro_wide {
@@ -49,13 +50,14 @@ struct WideBackend {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
-  std::vector<hipEvent_t> hist;
-  size_t hist_used = 0;
+  altro::LaunchRing ring;
   std::string err;
   // device
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr;
+  double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
+  std::vector<hipEvent_t> bench_ev;
   int *cur = nullptr, *ctype = nullptr, *rowk0 = nullptr, *rowk1 = nullptr, *rowc0 = nullptr, *rowcp = nullptr, *iters = nullptr, *iters_outer = nullptr,
       *status = nullptr, *noise_grp = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr, *noise = nullptr,
@@ -108,6 +110,8 @@ struct WideBackend {
     WCHK(hipStreamCreate(&stream));
     WCHK(hipEventCreate(&ev0));
     WCHK(hipEventCreate(&ev1));
+    ring.reset();
+    bench_ev.reserve(2);
     const size_t B = d.batch, N = d.N, n = d.n, m = d.m, z = n + m;
     int rc;
 #define DA_(p, c) if ((rc = dalloc(&p, (c)))) return rc
@@ -136,10 +140,12 @@ struct WideBackend {
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
-                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok};
+                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave};
     for (void* p : ptrs)
       if (p) hipFree(p);
-    for (auto e : hist) hipEventDestroy(e);
+    ring.destroy();
+    for (hipEvent_t e : bench_ev) hipEventDestroy(e);
+    bench_ev.clear();
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     if (stream) hipStreamDestroy(stream);
@@ -405,21 +411,68 @@ struct WideBackend {
     const int last_kref = mpc ? first_step + nsteps : kref;
     if (last_kref + d.N > Nt) WFAIL(ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
     if (mpc && ltv) WFAIL(ALTRO_ERR_UNSUPPORTED, "the device MPC loop needs time-invariant dynamics (per-knot dynamics change every step)");
+    hipEvent_t h0, h1;
+    WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
-    if (hist_used + 2 > hist.size())
-      for (int i = 0; i < 2; ++i) {
-        hipEvent_t e;
-        WCHK(hipEventCreate(&e));
-        hist.push_back(e);
-      }
-    WCHK(hipEventRecord(hist[hist_used], stream));
+    WCHK(hipEventRecord(h0, stream));
     hipLaunchKernelGGL(wide_kernel_for(d.m), dim3(d.batch), dim3(64), lds_bytes(), stream, params(), mpc, first_step, nsteps);
     WCHK(hipGetLastError());
-    WCHK(hipEventRecord(hist[hist_used + 1], stream));
-    hist_used += 2;
+    WCHK(hipEventRecord(h1, stream));
     WCHK(hipEventRecord(ev1, stream));
     timed = true;
     if (mpc) kref = first_step + nsteps;
+    return ALTRO_OK;
+  }
+
+  // altro_mpc_prepare_async: plant step + noise -> x0, reference window <- step + 1 (no shift, no solve)
+  int mpc_prepare(int step) {
+    if (step < 0) WFAIL(ALTRO_ERR_INVALID_ARG, "bad step");
+    if (noise && step + 1 > noise_steps) WFAIL(ALTRO_ERR_INVALID_ARG, "step outside the uploaded noise");
+    if (step + 1 + d.N > Nt) WFAIL(ALTRO_ERR_INVALID_ARG, "step runs past the end of the track");
+    if (ltv) WFAIL(ALTRO_ERR_UNSUPPORTED, "the device plant step needs time-invariant dynamics");
+    WCHK(hipSetDevice(device));
+    int rc = prepare_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wide_kernel_for(d.m), dim3(d.batch), dim3(64), lds_bytes(), stream, params(), 2, step, 1);
+    WCHK(hipGetLastError());
+    kref = step + 1;
+    return ALTRO_OK;
+  }
+
+  // benchmark_solve!(solver; samples, evals): see include/altro_batch.h
+  int benchmark_solve(int samples, int evals, float* sample_ms) {
+    if (samples < 1 || evals < 1) WFAIL(ALTRO_ERR_INVALID_ARG, "samples and evals must be positive");
+    WCHK(hipSetDevice(device));
+    const size_t B = d.batch, lx = (size_t)d.N * d.n, lu = (size_t)(d.N - 1) * d.m;
+    if (!Xsave) WCHK(hipMalloc(&Xsave, B * lx * sizeof(double)));
+    if (!Usave) WCHK(hipMalloc(&Usave, B * lu * sizeof(double)));
+    while (bench_ev.size() < 2) {
+      hipEvent_t e;
+      WCHK(hipEventCreate(&e));
+      bench_ev.push_back(e);
+    }
+    const dim3 gx((unsigned)((B * lx + 255) / 256)), gu((unsigned)((B * lu + 255) / 256));
+    hipLaunchKernelGGL(k_gather_plane, gx, dim3(256), 0, stream, Xsave, X, cur, lx, (int)B);  // Z0 = copy(get_trajectory(solver))
+    hipLaunchKernelGGL(k_gather_plane, gu, dim3(256), 0, stream, Usave, U, cur, lu, (int)B);
+    WCHK(hipGetLastError());
+    auto one = [&]() -> int {  // initial_trajectory!(solver, Z0); solve!(solver)
+      hipLaunchKernelGGL(k_scatter_plane, gx, dim3(256), 0, stream, X, Xsave, cur, lx, (int)B);
+      hipLaunchKernelGGL(k_scatter_plane, gu, dim3(256), 0, stream, U, Usave, cur, lu, (int)B);
+      return enqueue(0, 0, 0);
+    };
+    int rc = one();  // BenchmarkTools' warm-up evaluation
+    if (rc) return rc;
+    for (int s_ = 0; s_ < samples; ++s_) {
+      WCHK(hipEventRecord(bench_ev[0], stream));
+      for (int e = 0; e < evals; ++e)
+        if ((rc = one())) return rc;
+      WCHK(hipEventRecord(bench_ev[1], stream));
+      WCHK(hipEventSynchronize(bench_ev[1]));
+      float ms = 0.f;
+      WCHK(hipEventElapsedTime(&ms, bench_ev[0], bench_ev[1]));
+      if (sample_ms) sample_ms[s_] = ms / (float)evals;
+    }
+    WCHK(hipStreamSynchronize(stream));
     return ALTRO_OK;
   }
 
@@ -494,7 +547,7 @@ struct WideBackend {
   int timing_reset() {
     WCHK(hipSetDevice(device));
     WCHK(hipStreamSynchronize(stream));
-    hist_used = 0;
+    ring.reset();
     const size_t B = d.batch;
     for (long long* p : {n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok}) WCHK(hipMemset(p, 0, B * sizeof(long long)));
     return ALTRO_OK;
@@ -502,9 +555,9 @@ struct WideBackend {
   int timing_get(float* ms, int capacity, int* count) {
     WCHK(hipSetDevice(device));
     WCHK(hipStreamSynchronize(stream));
-    const int nl = (int)(hist_used / 2);
+    const int nl = (int)ring.readable();
     if (count) *count = nl;
-    for (int i = 0; i < nl && i < capacity && ms; ++i) WCHK(hipEventElapsedTime(&ms[i], hist[2 * i], hist[2 * i + 1]));
+    for (int i = 0; i < nl && i < capacity && ms; ++i) WCHK(ring.elapsed((size_t)i, &ms[i]));
     return ALTRO_OK;
   }
   int counters(long long* const src[3], int64_t* a, int64_t* b, int64_t* c) {

@@ -70,6 +70,20 @@ class BatchMPC:
         self.step_async(i)
         self.synchronize()
 
+    def step_benchmark(self, i=None, samples=5, evals=5):
+        """One MPC step exactly as the reference's loop body runs it (random_linear_problem.jl:121-161):
+        plant step + noise -> x0; update_trajectory!; RD.shift_fill!(Z); Altro.shift_fill!(conSet);
+        benchmark_solve!(altro, samples=5, evals=5).  The statistics read afterwards are those of the
+        last of the 1 + samples*evals repeated solves, as in the reference's result Dict.  Returns the
+        per-sample times (ms, whole batch)."""
+        i = self.i if i is None else i
+        s = self.solver
+        s._chk(s._L.altro_mpc_prepare_async(s.h, i))
+        api.shift_fill(s, True, True)
+        ms = api.benchmark_solve(s, samples, evals)
+        self.i = i + 1
+        return ms
+
     def x0(self):
         s = self.solver
         out = np.empty((s.B, s.n))
@@ -109,6 +123,7 @@ class TrackMPC:
     run_async = BatchMPC.run_async
     synchronize = BatchMPC.synchronize
     step = BatchMPC.step
+    step_benchmark = BatchMPC.step_benchmark
     x0 = BatchMPC.x0
 
 

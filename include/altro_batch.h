@@ -35,7 +35,9 @@ enum {
   ALTRO_ERR_INVALID_ARG = 1,
   ALTRO_ERR_UNSUPPORTED = 2, /* problem shape/constraint outside the built kernel set */
   ALTRO_ERR_HIP = 3,         /* HIP runtime failure (message has the HIP error string) */
-  ALTRO_ERR_STATE = 4        /* call sequence error (e.g. solve before set_dynamics) */
+  ALTRO_ERR_STATE = 4,       /* call sequence error (e.g. solve before set_dynamics) */
+  ALTRO_ERR_INTERNAL = 5     /* host allocation failure or any other C++ exception inside the library:
+                                caught at the boundary, never propagated to the caller */
 };
 
 /* Altro.TerminationStatus.  Only UNSOLVED and SOLVE_SUCCEEDED are named in the reference
@@ -167,6 +169,18 @@ int32_t altro_batch_solve(altro_handle* h);
 int32_t altro_batch_solve_async(altro_handle* h);
 int32_t altro_batch_synchronize(altro_handle* h);
 
+/* benchmark_solve!(solver; samples, evals): random_linear_problem.jl:161 (samples = 5, evals = 5),
+ * simple_rocket.jl:171, run_simple_rocket.jl:67,102, flexible_sat_mpc.jl:166.  Altro.jl's harness
+ * around BenchmarkTools: Z0 = copy of the solver's trajectory; then 1 warm-up evaluation and
+ * samples x evals timed evaluations of { initial_trajectory!(solver, Z0); solve!(solver) }.
+ * Only the primal trajectory is restored: with reset_duals = false (run_random_linear.jl:47) every
+ * repetition starts from the multipliers the previous one left, which is what the iteration counts
+ * and times stored in the reference's *.jld2 files measure (the statistics of the LAST repetition;
+ * random_linear_problem.jl:171-173).  On return the handle holds the result of the last repetition.
+ * sample_ms (may be NULL) receives `samples` values: device time of one sample divided by evals,
+ * i.e. BenchmarkTools' per-evaluation time of each sample, in ms for the whole batch.  Synchronous. */
+int32_t altro_batch_benchmark_solve(altro_handle* h, int32_t samples, int32_t evals, float* sample_ms);
+
 /* states(solver), controls(solver), Altro.get_duals: random_linear_problem.jl:177-181 */
 int32_t altro_batch_get_states(altro_handle* h, double* X);
 int32_t altro_batch_get_controls(altro_handle* h, double* U);
@@ -233,6 +247,11 @@ int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift);
  * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
  * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */
 int32_t altro_mpc_step_async(altro_handle* h, int32_t step);
+/* The first half of that sequence only, for harnesses that keep the reference's own call order
+ * around benchmark_solve! (random_linear_problem.jl:125-133): x0 <- A x_1 + B u_1 + noise_step*...,
+ * reference window <- step+1.  No shift_fill and no solve: follow with altro_batch_shift_fill and
+ * altro_batch_solve / altro_batch_benchmark_solve. */
+int32_t altro_mpc_prepare_async(altro_handle* h, int32_t step);
 /* The same for `nsteps` consecutive steps first_step .. first_step+nsteps-1 in ONE launch.
  * Instances are independent closed loops, so inside the launch each wavefront runs its own four
  * instances through all the steps without waiting for the rest of the batch; results are

@@ -191,6 +191,19 @@ class OracleSolver:
         lib().orc_solve(self.h)
         return self.stats()
 
+    def benchmark_solve(self, samples=5, evals=5):
+        """Altro.jl's benchmark_solve!(solver; samples, evals) (reference call site
+        random_linear_problem.jl:161): Z0 = copy of the trajectory; 1 warm-up + samples*evals
+        repetitions of { initial_trajectory!(solver, Z0); solve! }.  Only the primal trajectory is
+        restored (iLQR re-rolls the states out, so the controls are all that matters); duals and
+        penalties carry over from one repetition to the next.  Returns the stats of the last one."""
+        U0 = self.controls()
+        st = None
+        for _ in range(1 + samples * evals):
+            self.set_controls(U0)
+            st = self.solve()
+        return st
+
     def stats(self):
         return lib().orc_get_stats(self.h).contents
 

@@ -9,7 +9,15 @@ Fixtures produced:
                             (the only solver OUTPUT trajectory stored in the reference)
   ref_iteration_stats.json  ALTRO iteration-count / error statistics of the warm-started MPC
                             runs in horizon_comp.jld2, state_dim_comp.jld2, control_dim_comp.jld2
+  ref_rocket_step.json      benchmarks/rocket_landing/rocket.jld2 (`res` of ONE conic MPC step:
+                            iterations, costs, ALTRO-vs-conic-solver errors, times; `tols`) and the
+                            error-vs-tolerance table the same script wrote to
+                            figures/rocket_solver_tol.tikz (run_simple_rocket.jl:146-206,222)
+  ref_grasp_mpc_stats.json  benchmarks/grasp_optimization/grasp_benchmark_data.jld2: per comparison
+                            solver (ECOS, COSMO, Mosek) and horizon N_mpc in Ns, ALTRO's per-step
+                            iteration counts, ALTRO-vs-solver errors and times (grasp_mpc.jl:96-108)
 """
+import re
 import json
 import os
 import struct
@@ -137,6 +145,68 @@ def extract_iter_stats():
     return summ
 
 
+def extract_rocket():
+    path = os.path.join(REF, "benchmarks/rocket_landing/rocket.jld2")
+    arrs = numeric_arrays(path)
+    by_shape = {}
+    for pos, sh, a in arrs:
+        by_shape.setdefault((tuple(sh), a.dtype.kind), []).append(a.tolist())
+    # res = Dict(:time [1x2], :iter [1x2], :cost [1x3], :err_traj [1x3], :status) of run_Rocket_MPC(num_iters=1)
+    # (simple_rocket.jl:206); HDF5 shapes are reversed, column 1 = ALTRO, column 2 = the conic solver
+    out = {"source": "benchmarks/rocket_landing/rocket.jld2 (run_simple_rocket.jl:206)",
+           "iter_altro_other": by_shape[((2, 1), "i")][0],
+           "cost_altro_equiv_solver": by_shape[((3, 1), "f")][0],
+           "err_traj_state_control_dynamics": by_shape[((3, 1), "f")][1],
+           "time_ms_altro_other": by_shape[((2, 1), "f")][0],
+           "tols": by_shape[((6,), "f")][0]}
+    # tol_comp is stored as an SMatrix (a compound type the scanner skips); the same numbers were written as
+    # plot coordinates by run_simple_rocket.jl:213-226
+    tikz = open(os.path.join(REF, "figures/rocket_solver_tol.tikz")).read()
+    legend = re.search(r"\\legend\{(.*)\}", tikz).group(1)
+    names = re.findall(r"\{(\w+)\}", legend)
+    blocks = re.findall(r"coordinates \{(.*?)\}", tikz, re.S)
+    out["tol_comp"] = {"source": "figures/rocket_solver_tol.tikz",
+                       "what": "max(state, control) inf-norm error of each solver's one-step MPC solution at solver tolerance tol"}
+    for name, blk in zip(names, blocks):
+        pts = re.findall(r"\(([^,]+),([^)]+)\)", blk)
+        out["tol_comp"][name] = [[float(a), float(b)] for a, b in pts]
+    json.dump(out, open(os.path.join(HERE, "ref_rocket_step.json"), "w"), indent=1)
+    return out
+
+
+def extract_grasp_benchmark():
+    path = os.path.join(REF, "benchmarks/grasp_optimization/grasp_benchmark_data.jld2")
+    arrs = numeric_arrays(path)
+    Ns = [a.tolist() for pos, sh, a in arrs if sh == [5] and a.dtype.kind == "i"][0]
+    # results[solver][N] = (Dict(:time [T x 2], :iter [T], :err_traj [T x 2]), ...), T = 251 - N_mpc
+    # (grasp_benchmark.jl:66-85, grasp_mpc.jl:96-108); file order: :iter, :err_traj, :time per run
+    runs, cur = [], None
+    for pos, sh, a in arrs:
+        if a.dtype.kind != "f" or not sh or sh[-1] < 100:
+            continue
+        if len(sh) == 1:
+            cur = {"steps": sh[0], "iter": [int(v) for v in a]}
+            runs.append(cur)
+        elif cur is not None and sh == [2, cur["steps"]]:
+            T = cur["steps"]
+            if "err_state" not in cur:
+                cur["err_state"], cur["err_control"] = a[:T].tolist(), a[T:2 * T].tolist()
+            else:
+                cur["time_ms_altro"], cur["time_ms_other"] = a[:T].tolist(), a[T:2 * T].tolist()
+    assert len(runs) == 15 and all("time_ms_other" in r for r in runs)
+    names = ["ECOS", "COSMO", "Mosek"]          # order of `optimizers`, grasp_benchmark.jl:36-61
+    out = {"source": "benchmarks/grasp_optimization/grasp_benchmark_data.jld2 (grasp_benchmark.jl:66-88)", "Ns": Ns, "runs": []}
+    for i, r in enumerate(runs):
+        it = np.array(r["iter"])
+        out["runs"].append({"solver": names[i // 5], "N_mpc": Ns[i % 5], "steps": r["steps"], "iter": r["iter"],
+                            "iter_median": float(np.median(it)), "iter_mean": float(it.mean()), "iter_max": int(it.max()),
+                            "iter_min": int(it.min()),
+                            "err_state_median": float(np.median(r["err_state"])), "err_control_median": float(np.median(r["err_control"])),
+                            "time_ms_altro_mean": float(np.mean(r["time_ms_altro"])), "time_ms_other_mean": float(np.mean(r["time_ms_other"]))})
+    json.dump(out, open(os.path.join(HERE, "ref_grasp_mpc_stats.json"), "w"))
+    return out
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present; fixtures are already committed")
@@ -144,3 +214,8 @@ if __name__ == "__main__":
     print("grasp arrays:", [(a["hdf5_shape"], len(a["values"])) for a in g["arrays"]])
     s = extract_iter_stats()
     print(json.dumps(s, indent=1))
+    r = extract_rocket()
+    print(json.dumps(r, indent=1))
+    gb = extract_grasp_benchmark()
+    for run in gb["runs"]:
+        print({k: v for k, v in run.items() if k != "iter"})

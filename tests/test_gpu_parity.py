@@ -148,48 +148,80 @@ def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N, lin):
     assert nact > 20      # swing legs sit on the f_z >= 0 bound: the contact switches are exercised
 
 
-def test_reference_sweeps_reproduce_the_stored_iteration_statistics():
-    """run_random_linear.jl:110-153 end to end on the GPU: the horizon sweep (n = 12, m = 6,
-    N in 11..101), the state-dimension sweep (n in 2..55, m = 2, N = 21) and the control-dimension
-    sweep (m in 2..25, n = 30, N = 21), 100 MPC steps each, here for 32 random problems per point
-    instead of one.  The reference stored the per-step iteration counts of its runs
-    (horizon_comp.jld2, state_dim_comp.jld2, control_dim_comp.jld2 -> tests/golden/
-    ref_iteration_stats.json: median 2, one point with median 3, maximum 5, every solve
-    SOLVE_SUCCEEDED); the same statistics must come out here."""
+def test_benchmark_solve_protocol_matches_oracle(oracle):
+    """benchmark_solve!(altro, samples=5, evals=5) inside the MPC loop (random_linear_problem.jl:121-173):
+    altro_mpc_prepare_async + altro_batch_shift_fill + altro_batch_benchmark_solve against the oracle
+    driven through the same sequence (restore the primal trajectory only, 26 repeated solves)."""
+    B, S = 6, 6
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=4)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    for o in orcs:
+        o.solve()
+    for i in range(S):
+        ms = mp.step_benchmark(i, samples=5, evals=5)
+        assert ms.shape == (5,) and np.all(ms > 0)
+        st = altro.stats(mp.solver)
+        X, U = altro.states(mp.solver), altro.controls(mp.solver)
+        for b, o in enumerate(orcs):
+            mpc_update(o, pb, b, i)
+            so = o.benchmark_solve(samples=5, evals=5)
+            check_against_oracle(st, X, U, b, o, so)
+            lam_o = o.duals(0).reshape(pb.N - 1, 2, pb.n + pb.m)
+            assert rel_err(altro.get_duals(mp.solver)[b], lam_o) <= RTOL
+    # the generic form on a cold problem with reset_duals = true: every repetition is the same solve
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.x0 = prob.x0 + 0.5
+    cold = altro.ALTROSolver(prob, altro.SolverOptions(cost_tolerance=1e-4, constraint_tolerance=1e-4, penalty_initial=1000.0, penalty_scaling=100.0))
+    altro.solve(cold)
+    it1, J1, U1 = altro.iterations(cold).copy(), altro.cost(cold).copy(), altro.controls(cold)
+    altro.initial_controls(cold, prob.U0)
+    altro.benchmark_solve(cold, samples=2, evals=2)
+    assert np.array_equal(altro.iterations(cold), it1) and np.array_equal(altro.cost(cold), J1)
+    assert np.array_equal(altro.controls(cold), U1)
+
+
+def test_reference_sweeps_reproduce_the_stored_iteration_statistics_point_by_point():
+    """run_random_linear.jl:108-153 end to end on the GPU, in the reference's own protocol: the horizon
+    sweep (n = 12, m = 6, N in 11..101), the state-dimension sweep (n in 2..55, m = 2, N = 21) and the
+    control-dimension sweep (m in 2..25, n = 30, N = 21), 100 MPC steps each, every step ending in
+    benchmark_solve!(altro, samples=5, evals=5) and iterations(altro) read afterwards
+    (random_linear_problem.jl:161,171) -- the numbers stored in horizon_comp.jld2, state_dim_comp.jld2,
+    control_dim_comp.jld2 (tests/golden/ref_iteration_stats.json) are the counts of the LAST of the 26
+    repeated solves, which start from the multipliers the earlier ones converged (reset_duals=false and
+    benchmark_solve! restores only the primal trajectory).  Each stored point is compared with the same
+    point here (8 random problems instead of the reference's one).  tests/test_oracle.py holds the same
+    comparison for the oracle and the note on the one stored outlier (n = 15)."""
     import json
     import os
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_iteration_stats.json")))["stats"]
-    ref_max = max(p["altro_max"] for pts in gold.values() for p in pts)
-    ref_mean = max(p["altro_mean"] for pts in gold.values() for p in pts)
-    assert ref_max == 5 and 3.0 < ref_mean < 3.6
-    B, S = 32, 100
-    points = ([(12, 6, N) for N in (11, 31, 51, 71, 101)] + [(n, 2, 21) for n in (2, 15, 25, 35, 45, 55)] +
-              [(30, m, 21) for m in (2, 6, 10, 15, 20, 25)])
-    for n, m, N in points:
-        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=10)
+    B, S = 8, 100
+    points = ([("horizon_comp.jld2", i, (12, 6, N), 1) for i, N in enumerate((11, 31, 51, 71, 101))] +
+              [("state_dim_comp.jld2", i, (n, 2, 21), 10) for i, n in enumerate((2, 15, 25, 35, 45, 55))] +
+              [("control_dim_comp.jld2", i, (30, m, 21), 15) for i, m in enumerate((2, 6, 10, 15, 20, 25))])
+    for key, idx, (n, m, N), seed in points:
+        g = gold[key][idx]
+        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=seed)
         mp = altro.mpc.BatchMPC(pb)
         mp.initial_solve()
         its = np.zeros((S, B), dtype=int)
-        ok = True
-        for i0 in range(0, S, 10):          # ten fused steps per launch: per-step counts from the stats of each
-            for i in range(i0, i0 + 10):
-                mp.step_async(i)
-                mp.synchronize()
-                st = altro.stats(mp.solver)
-                its[i] = st.iterations
-                ok = ok and bool(np.all(st.status == altro.SOLVE_SUCCEEDED))
-        assert ok, (n, m, N)
-        assert np.median(its) in (2.0, 3.0), (n, m, N, np.median(its))
-        # the stored means are 2.0 .. 2.2 with one problem at 3.41: instance-to-instance spread is that large
-        assert its.mean() <= ref_mean + 0.6, (n, m, N, its.mean())
-        per = its.mean(axis=0)          # one number per random problem, like the reference's single run
-        # the reference has 100 samples of ONE random problem per point (max 5 everywhere); over 32 problems
-        # the tail is a little heavier where many of the m controls ride their bounds
-        assert (its <= ref_max).mean() >= 0.75, (n, m, N, (its <= ref_max).mean())
-        assert per.min() <= 2.5, (n, m, N, per.min())      # some problems are as easy as the reference's
-        print("sweep point n=%d m=%d N=%d: iterations median %.0f mean %.2f max %d, P(<=5) %.3f; per-problem means min %.2f median %.2f max %.2f" % (
-            n, m, N, np.median(its), its.mean(), its.max(), (its <= ref_max).mean(), per.min(), np.median(per), per.max()))
-        assert its.min() >= 2
+        for i in range(S):
+            mp.step_benchmark(i, samples=5, evals=5)
+            st = altro.stats(mp.solver)
+            its[i] = st.iterations
+            assert np.all(st.status == altro.SOLVE_SUCCEEDED), (n, m, N, i)
+        print("sweep point n=%d m=%d N=%d: reference mean %.2f max %d | here mean %.2f median %.0f max %d, per-problem means %.2f..%.2f" % (
+            n, m, N, g["altro_mean"], g["altro_max"], its.mean(), np.median(its), its.max(), its.mean(0).min(), its.mean(0).max()))
+        assert its.min() == 2 and np.median(its) == 2, (n, m, N)
+        if (n, m, N) == (15, 2, 21):   # the stored outlier: all of its 100 solves took 3-4 iterations (tests/test_oracle.py)
+            assert g["altro_min"] == 3 and its.mean() < g["altro_mean"]
+            continue
+        assert abs(its.mean() - g["altro_mean"]) <= 0.2, (n, m, N, its.mean(), g["altro_mean"])
+        # 800 solves here against the reference's 100: the maximum is a tail statistic, so bound the tail's weight
+        assert (its > g["altro_max"] + 1).mean() <= 0.01 and its.max() <= g["altro_max"] + 6, (n, m, N, its.max(), g["altro_max"])
+        # the reference's single problem must sit inside the spread of the 8 problems here
+        assert its.mean(0).min() - 0.1 <= g["altro_mean"] <= its.mean(0).max() + 0.15, (n, m, N, its.mean(0), g["altro_mean"])
 
 
 def test_cold_solve_far_from_reference_matches_oracle(oracle):

@@ -123,3 +123,126 @@ def test_grasp_cold_solve_matches_reference_trajectory(oracle):
     assert st2.status == 1 and st2.iterations <= 25 and st2.iterations_outer <= 6
     assert np.abs(s2.states()[:, 1] - y).max() < 1e-3 and np.abs(s2.controls()[:, 1:3] - F1).max() < 1e-3
     assert np.abs(X[:, 0]).max() < 1e-6 and np.abs(U[:, [0, 3]]).max() < 1e-6     # motion stays in the y-z plane
+
+
+def _grasp_mpc_iterations(oracle, gp, Xt, Ut, Nm, steps, seed, soc_second_order=1):
+    """run_grasp_mpc (grasp_mpc.jl:8-104): solve, then per step mpc_update! (1 % plant noise, retarget,
+    primal shift, REWRITE of the per-knot constraint data), dual shift, ONE solve! -- no
+    benchmark_solve! here, and reset_duals stays true (grasp_benchmark.jl:26-34)."""
+    import copy
+    mpc_opts = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-3, constraint_tolerance=1e-4,
+                    penalty_initial=10000.0, penalty_scaling=100.0, soc_second_order=soc_second_order)
+
+    def window(k0):
+        return [P.ConstraintSpec(c.kind, c.sense, 0, Nm - 2, A=c.A[k0:k0 + Nm - 1].copy(), b=c.b[k0:k0 + Nm - 1].copy())
+                for c in gp.constraints[1:]]
+
+    tp = copy.copy(gp)
+    tp.N, tp.Q, tp.R, tp.Qf = Nm, np.full(6, 1e3), np.full(6, 1.0), np.full(6, 10.0)   # grasp_benchmark.jl:79-80
+    tp.constraints = window(0)
+    o = rocket_oracle(oracle, tp, Xt[0], mpc_opts, Xt[:Nm], Ut[:Nm - 1], U0=Ut[:Nm - 1])
+    assert o.solve().status == 1
+    rng = np.random.default_rng(seed)
+    its, ok = [], 0
+    for i in range(1, steps + 1):
+        xn = o.plant_step()
+        o.set_initial_state(xn + rng.standard_normal(6) * np.abs(xn).max() / 100.0)
+        o.set_reference(Xt[i:i + Nm], Ut[i:i + Nm - 1])
+        o.shift_fill(True, False)
+        for ci, c in enumerate(window(i)):
+            o.update_constraint_data(o.con_ids[ci], c.A, c.b)
+        o.shift_fill(False, True)
+        so = o.solve()
+        its.append(so.iterations)
+        ok += so.status == 1
+    return np.array(its), ok
+
+
+def test_grasp_mpc_iteration_statistics_against_reference(oracle):
+    """benchmarks/grasp_optimization/grasp_benchmark_data.jld2 (tests/golden/ref_grasp_mpc_stats.json) holds
+    ALTRO's per-step iteration counts of the conic grasp MPC loop for N_mpc = 11..51, three times over (once
+    per comparison solver, different noise each time): 15 runs of 200-240 steps, every one with median 3,
+    minimum 2, mean 3.3-4.0, maximum 8-20.  The same loop on the restatement (cold solve at N = 251, tracking
+    problem, per-step constraint rewrites, duals reset every solve; own noise samples):
+
+      * what is reproduced: every solve SOLVE_SUCCEEDED, minimum 2, the bulk at 2-4 iterations, maxima of the
+        same order;
+      * OPEN FIDELITY GAP (DESIGN.md "Oracle and parity"): the restatement needs about one iteration more per
+        solve on average (mean 4.5 with the Gauss-Newton cone Hessian, 5.5 with the projection-curvature term,
+        against 3.3-4.0) -- 20 % of its solves take 7+ iterations where 5 % of the reference's do.  The
+        converged answers agree (the stored grasp trajectory is reproduced to 3e-7 above); what differs is
+        Altro.jl's iterate path on cold duals at penalty 1e4, which nothing in the reference records.
+    The bounds below pin today's behaviour so that a change of the restatement shows up here."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_grasp_mpc_stats.json")))
+    runs = gold["runs"]
+    assert len(runs) == 15 and all(r["iter_median"] == 3.0 and r["iter_min"] == 2 for r in runs)
+    mean_lo, mean_hi = min(r["iter_mean"] for r in runs), max(r["iter_mean"] for r in runs)
+    assert 3.3 < mean_lo and mean_hi < 4.05
+    max_hi = max(r["iter_max"] for r in runs)
+    gp = P.gen_grasp_problem(N=251, tf=6.0)                     # GraspProblem(o, 251): grasp_benchmark.jl:72, grasp_problem.jl:1
+    cold = rocket_oracle(oracle, gp, gp.x0, dict(cost_tolerance=1e-6, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-6,
+                                                 iterations=5000, iterations_outer=60, iterations_inner=300))
+    assert cold.solve().status == 1
+    Xt, Ut = cold.states(), cold.controls()
+    for Nm, seed in ((11, 1), (31, 2), (51, 3)):
+        steps = 251 - Nm
+        for so2, gap, med_hi in ((0, 1.3, 4), (1, 2.4, 5)):     # Gauss-Newton cone Hessian / with the curvature term
+            its, ok = _grasp_mpc_iterations(oracle, gp, Xt, Ut, Nm, steps, seed, so2)
+            assert ok >= steps - 2, (Nm, ok)                    # SOLVE_SUCCEEDED (the reference's loop does not check)
+            assert its.min() == 2 and 3 <= np.median(its) <= med_hi, (Nm, so2, np.median(its), its.min())
+            assert mean_lo <= its.mean() <= mean_hi + gap, (Nm, so2, its.mean(), mean_lo, mean_hi)
+            assert (its <= 4).mean() >= 0.4 and its.max() <= 3 * max_hi, (Nm, so2, its.max())
+
+
+def test_rocket_mpc_step_error_vs_solver_tolerance_follows_the_reference_table(oracle):
+    """benchmarks/rocket_landing/rocket.jld2 + figures/rocket_solver_tol.tikz (tests/golden/ref_rocket_step.json):
+    run_simple_rocket.jl:146-206 solves ONE conic MPC step (N_mpc = 21, first solve at tol0 = 1e-6, then
+    mpc_update with the position / velocity noise of simple_rocket.jl:65-71) at solver tolerances 1e-2 .. 1e-12
+    (cost, constraint and both gradient tolerances all set to tol) and stores the trajectory error against a
+    tight solution: 0.47 at 1e-2, then a plateau of 5.4e-7 from 1e-4 on -- ALTRO's conic AL is at its answer as
+    soon as the duals are warm -- and the stored `res` of one such step (9 iterations, ALTRO-vs-conic-solver
+    error 1.5e-9 in the states, 4e-7 in the controls).  The Julia noise sample is not reproducible, so the
+    table is pinned in shape: coarse at 1e-2, at the 1e-6 level from tol = 1e-6 on, a handful of iterations."""
+    import json
+    import os
+    from helpers import ROCKET_COLD_OPTS, ROCKET_MPC_OPTS
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_rocket_step.json")))
+    tab = dict((t, e) for t, e in gold["tol_comp"]["ALTRO"])
+    assert gold["iter_altro_other"][0] == 9 and tab[1e-2] > 0.1 and all(tab[t] < 1e-6 for t in (1e-4, 1e-6, 1e-8, 1e-10, 1e-12))
+    assert gold["err_traj_state_control_dynamics"][0] < 1e-8 and gold["err_traj_state_control_dynamics"][1] < 1e-6
+    Nt, dt, Nm = 301, 0.05, 21
+    rp = P.gen_rocket_problem(N=Nt, tf=(Nt - 1) * dt, Qfk=1e4, Rk=1.0, theta_thrust_max=5.0, theta_glideslope=45.0)
+    cold = rocket_oracle(oracle, rp, rp.x0, ROCKET_COLD_OPTS)
+    assert cold.solve().status == 1
+    Xt, Ut = cold.states(), cold.controls()
+    tp = P.gen_rocket_problem(N=Nm, tf=dt * (Nm - 1), include_goal=False, theta_thrust_max=5.0, theta_glideslope=45.0)
+    tp.Q, tp.R, tp.Qf = np.full(6, 10.0), np.full(3, 0.1), np.full(6, 10.0)           # gen_tracking_problem, mpc.jl:12-14
+    keys = ("constraint_tolerance", "cost_tolerance", "cost_tolerance_intermediate", "gradient_tolerance")
+
+    def one_step(tol, seed):
+        o0 = dict(ROCKET_MPC_OPTS, **{k: 1e-6 for k in keys})                           # tol0 (simple_rocket.jl:122-128)
+        o = rocket_oracle(oracle, tp, Xt[0], o0, Xt[:Nm], Ut[:Nm - 1], U0=Ut[:Nm - 1])
+        assert o.solve().status == 1
+        o1 = dict(ROCKET_MPC_OPTS, iterations=2000, iterations_outer=60, gradient_tolerance_intermediate=tol, **{k: tol for k in keys})
+        o.set_opts(oracle.default_opts(**o1))
+        rng = np.random.default_rng(seed)
+        xn = o.plant_step()
+        o.set_initial_state(xn + np.r_[rng.standard_normal(3) * np.linalg.norm(xn[:3]) / 1000.0,
+                                       rng.standard_normal(3) * np.linalg.norm(xn[3:]) / 100.0])
+        o.set_reference(Xt[1:1 + Nm], Ut[1:Nm])
+        o.shift_fill(True, True)
+        so = o.solve()
+        return o.states(), o.controls(), so
+
+    for seed in (1, 2):
+        Xr, Ur, _ = one_step(1e-13, seed)
+        err, its = {}, {}
+        for tol in (1e-2, 1e-4, 1e-6, 1e-8, 1e-10):
+            X, U, so = one_step(tol, seed)
+            assert so.status == 1, (tol, so.status)
+            err[tol], its[tol] = max(np.abs(X - Xr).max(), np.abs(U - Ur).max()), so.iterations
+        assert err[1e-2] > 1e-3 and err[1e-2] > 50 * err[1e-4], (seed, err)            # coarse, then a sharp drop
+        assert all(err[t] < 2e-6 for t in (1e-6, 1e-8, 1e-10)), (seed, err)             # the plateau level of the table
+        assert 3 <= its[1e-4] <= 12 and its[1e-10] <= 25, (seed, its)                   # stored step: 9 iterations
