@@ -7,7 +7,7 @@ restates the reference's problem generators and MPC harness (problems.py, mpc.py
 """
 from . import _lib, mpc, parallel, problems  # noqa: F401
 from ._lib import SOLVE_SUCCEEDED, STATUS_NAMES  # noqa: F401
-from .api import alpha_trace, gains, set_dynamics  # noqa: F401
+from .api import alpha_trace, gains, set_dynamics, set_dynamics_track  # noqa: F401
 from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, GoalConstraint, LinearConstraint,
                   LinearModel, NormConstraint, Problem,  # noqa: F401
                   SolverOptions, TrackingObjective, benchmark_solve, controls, cost, get_duals, initial_controls,

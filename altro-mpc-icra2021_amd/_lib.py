@@ -33,7 +33,7 @@ EXPORTS = [
     "altro_batch_get_work_counters", "altro_batch_get_wave_cycles", "altro_batch_get_solve_counters", "altro_mpc_run_async",
     "altro_mpc_set_noise_model", "altro_mpc_set_shift", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
-    "altro_mpc_prepare_async", "altro_batch_benchmark_solve",
+    "altro_mpc_prepare_async", "altro_batch_benchmark_solve", "altro_mpc_set_dynamics_track",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -51,7 +51,7 @@ class Opts(C.Structure):
         "bp_reg_initial", "bp_reg_increase_factor", "bp_reg_max", "bp_reg_min", "bp_reg_fp")] + \
         [(k, C.c_int32) for k in (
             "iterations", "iterations_inner", "iterations_outer", "iterations_linesearch",
-            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order")]
+            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order", "strict")]
 
 
 class AltroError(RuntimeError):
@@ -134,6 +134,7 @@ def lib():
     L.altro_mpc_step_async.argtypes = [H, C.c_int32]
     L.altro_batch_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.altro_mpc_prepare_async.argtypes = [H, C.c_int32]
+    L.altro_mpc_set_dynamics_track.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32, C.c_int32]
     L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name != "altro_last_error":

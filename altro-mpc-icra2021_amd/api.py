@@ -228,6 +228,22 @@ def set_dynamics(solver, mdl):
     solver._chk(solver._L.altro_batch_set_dynamics(solver.h, _p(Ac), _p(Bc), _p(dc), int(mdl.per_knot), int(per_instance)))
 
 
+def set_dynamics_track(solver, A, B, d=None, step_stride=1):
+    """Per-knot dynamics of every MPC step, uploaded once for the device-resident loop
+    (altro_mpc_set_dynamics_track; reference: update_dynamics_matrices!, altro_solver.jl:5-37).
+    A: (nblocks, n, n) shared or (B, nblocks, n, n) per instance, B and d likewise; the solve of MPC
+    step i reads block (i + 1) * step_stride + k for knot k (step_stride 1: blocks indexed by absolute
+    knot; N - 1: one table per step)."""
+    A = np.asarray(A, dtype=np.float64)
+    Bm = np.asarray(B, dtype=np.float64)
+    per_instance = A.ndim == 4
+    nblocks = A.shape[-3]
+    Ac = _c(np.swapaxes(A, -1, -2))
+    Bc = _c(np.swapaxes(Bm, -1, -2))
+    dc = _c(d) if d is not None else None
+    solver._chk(solver._L.altro_mpc_set_dynamics_track(solver.h, _p(Ac), _p(Bc), _p(dc), int(nblocks), int(step_stride), int(per_instance)))
+
+
 def set_options(solver, **kw):
     for k, v in kw.items():
         setattr(solver.opts, k, v)

@@ -413,6 +413,7 @@ int32_t altro_default_opts(altro_opts* o) {
     o->reset_penalties = 1;
     o->bp_reg = 0;
     o->soc_second_order = 1;
+    o->strict = 0;
     return ALTRO_OK;
   });
 }
@@ -613,33 +614,39 @@ int32_t altro_batch_destroy(altro_handle* h) {
   return ALTRO_OK;
 }
 
+// Per-knot (LTV) dynamics exist on the one-wave-per-instance kernel only.  A 16-lane handle on which nothing
+// but create has happened moves there; the Julia model is fixed when ALTROSolver(prob, opts) is built
+// (ALTROParams.jl:61,96), so set_dynamics is the first call of every harness.
+static int migrate_to_wide(altro_handle* h) {
+  if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
+    FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
+                                   "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
+  altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
+  if (!wb) FAIL(h, ALTRO_ERR_INTERNAL, "out of host memory");
+  // the wide backend is created BEFORE the 16-lane one is released: if it cannot be (e.g. no device
+  // memory for its arrays) the handle stays a working 16-lane handle and only this call fails
+  const int rc = wb->create(&h->d, &h->o, h->device);
+  if (rc) {
+    h->err = wb->err;
+    wb->destroy();
+    delete wb;
+    return rc;
+  }
+  free_dpp_backend(h);
+  h->wide = wb;
+  return ALTRO_OK;
+}
+
 int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double* B, const double* f,
                                  int32_t per_knot, int32_t per_instance) {
   return guard(h, [&]() -> int32_t {
     WIDE_FWD(h, set_dynamics(A, B, f, per_knot, per_instance));
     if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
     if (per_knot) {
-      // Per-knot (LTV) dynamics exist on the one-wave-per-instance kernel only.  A handle on which nothing
-      // but create has happened moves there; the Julia model is fixed when ALTROSolver(prob, opts) is built
-      // (ALTROParams.jl:61,96), so set_dynamics is the first call of every harness.
-      if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
-        FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
-                                       "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
-      altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
-      if (!wb) FAIL(h, ALTRO_ERR_INTERNAL, "out of host memory");
-      // the wide backend is created BEFORE the 16-lane one is released: if it cannot be (e.g. no device
-      // memory for its arrays) the handle stays a working 16-lane handle and only this call fails
-      const int rc = wb->create(&h->d, &h->o, h->device);
-      if (rc) {
-        h->err = wb->err;
-        wb->destroy();
-        delete wb;
-        return rc;
-      }
-      free_dpp_backend(h);
-      h->wide = wb;
-      const int rc2 = wb->set_dynamics(A, B, f, per_knot, per_instance);
-      if (rc2) h->err = wb->err;
+      const int rc = migrate_to_wide(h);
+      if (rc) return rc;
+      const int rc2 = h->wide->set_dynamics(A, B, f, per_knot, per_instance);
+      if (rc2) h->err = h->wide->err;
       return rc2;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1290,6 +1297,19 @@ int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps)
 }
 
 int32_t altro_mpc_step_async(altro_handle* h, int32_t step) { return altro_mpc_run_async(h, step, 1); }
+
+int32_t altro_mpc_set_dynamics_track(altro_handle* h, const double* A, const double* B, const double* f, int32_t nblocks,
+                                     int32_t step_stride, int32_t per_instance) {
+  return guard(h, [&]() -> int32_t {
+    if (!h || !A || !B) return ALTRO_ERR_INVALID_ARG;
+    if (!h->wide) {
+      const int rc = migrate_to_wide(h);
+      if (rc) return rc;
+    }
+    WIDE_FWD(h, mpc_set_dynamics_track(A, B, f, nblocks, step_stride, per_instance));
+    return ALTRO_ERR_STATE;
+  });
+}
 
 int32_t altro_mpc_prepare_async(altro_handle* h, int32_t step) {
   return guard(h, [&]() -> int32_t {

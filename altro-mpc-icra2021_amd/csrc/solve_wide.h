@@ -56,6 +56,11 @@ struct Params {
   int con_static;  // nonzero: no constraint block has per-knot data, the row table is the same at every knot of a row's
                    // range and stays in LDS (bits: 1 rollouts, 2 row values of expansion / dual update, 4 expansion tables)
   int kref;
+  // per-knot dynamics: every instance owns dyn_blocks knot blocks; window knot k of a solve whose reference
+  // window starts at kref reads block kref * dyn_step_stride + k.  altro_batch_set_dynamics(per_knot) gives
+  // dyn_blocks = N - 1, stride 0; altro_mpc_set_dynamics_track a long table with stride 1 (blocks indexed by
+  // absolute knot, like the reference track) or N - 1 (one full table per MPC step).
+  int dyn_blocks, dyn_step_stride;
   altro_opts o;
 };
 
@@ -257,7 +262,8 @@ struct Solver {
   }
 
   __device__ __forceinline__ size_t dynblk(int k) const {
-    return (size_t)(P.dyn_per_instance ? inst : 0) * (P.ltv ? (N - 1) : 1) + (P.ltv ? k : 0);
+    return (size_t)(P.dyn_per_instance ? inst : 0) * (P.ltv ? P.dyn_blocks : 1) +
+           (P.ltv ? (size_t)kref * P.dyn_step_stride + k : 0);
   }
   __device__ __forceinline__ const double* Ak(int k) const { return P.A + dynblk(k) * n * n; }
   __device__ __forceinline__ const double* Bk(int k) const { return P.Bm + dynblk(k) * n * m; }

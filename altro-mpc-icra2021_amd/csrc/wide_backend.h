@@ -66,6 +66,7 @@ struct WideBackend {
             *n_ok = nullptr;
   size_t stage_bytes = 0;
   int Nt = 0, kref = 0, noise_steps = 0, noise_mode = 0, mpc_shift = 1;
+  int dyn_blocks = 1, dyn_step_stride = 0;
   bool ltv = false, dyn_per_instance = false, have_dyn = false, have_cost = false, have_ref = false;
   int box_k0 = 0, box_k1 = -1, box_id = -1;
   struct Block {
@@ -151,11 +152,13 @@ struct WideBackend {
     if (stream) hipStreamDestroy(stream);
   }
 
-  int set_dynamics(const double* A_, const double* B_, const double* f_, int per_knot, int per_instance) {
+  // blocks_per_instance knot blocks per instance (1: time-invariant)
+  int upload_dynamics(const double* A_, const double* B_, const double* f_, size_t blocks_per_instance, int per_instance) {
     if (!A_ || !B_) return ALTRO_ERR_INVALID_ARG;
     WCHK(hipSetDevice(device));
+    WCHK(hipStreamSynchronize(stream));
     const size_t n = d.n, m = d.m;
-    const size_t blocks_ = (per_instance ? (size_t)d.batch : 1) * (per_knot ? (size_t)(d.N - 1) : 1);
+    const size_t blocks_ = (per_instance ? (size_t)d.batch : 1) * blocks_per_instance;
     for (double** p : {&A, &Bm, &f})
       if (*p) { WCHK(hipFree(*p)); *p = nullptr; }
     WCHK(hipMalloc(&A, blocks_ * n * n * sizeof(double)));
@@ -165,11 +168,32 @@ struct WideBackend {
     WCHK(hipMemcpy(Bm, B_, blocks_ * n * m * sizeof(double), hipMemcpyHostToDevice));
     if (f_) WCHK(hipMemcpy(f, f_, blocks_ * n * sizeof(double), hipMemcpyHostToDevice));
     else WCHK(hipMemset(f, 0, blocks_ * n * sizeof(double)));
-    ltv = per_knot != 0;
     dyn_per_instance = per_instance != 0;
     have_dyn = true;
     return ALTRO_OK;
   }
+
+  int set_dynamics(const double* A_, const double* B_, const double* f_, int per_knot, int per_instance) {
+    const int rc = upload_dynamics(A_, B_, f_, per_knot ? (size_t)(d.N - 1) : 1, per_instance);
+    if (rc) return rc;
+    ltv = per_knot != 0;
+    dyn_blocks = per_knot ? d.N - 1 : 1;
+    dyn_step_stride = 0;
+    return ALTRO_OK;
+  }
+
+  // altro_mpc_set_dynamics_track: see include/altro_batch.h
+  int mpc_set_dynamics_track(const double* A_, const double* B_, const double* f_, int nblocks, int step_stride, int per_instance) {
+    if (nblocks < d.N - 1 || (step_stride != 1 && step_stride != d.N - 1)) WFAIL(ALTRO_ERR_INVALID_ARG, "bad dynamics track shape");
+    const int rc = upload_dynamics(A_, B_, f_, (size_t)nblocks, per_instance);
+    if (rc) return rc;
+    ltv = true;
+    dyn_blocks = nblocks;
+    dyn_step_stride = step_stride;
+    return ALTRO_OK;
+  }
+  // last reference-window start the dynamics table covers
+  bool dyn_covers(int kref_) const { return !ltv || (long long)kref_ * dyn_step_stride + (d.N - 1) <= (long long)dyn_blocks; }
 
   int set_tracking_cost(const double* Qd, const double* Rd, const double* Qfd, double dt) {
     if (!Qd || !Rd || !Qfd || !(dt > 0.0)) return ALTRO_ERR_INVALID_ARG;
@@ -375,6 +399,7 @@ struct WideBackend {
     p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok;
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
+    p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
     p.o = o;
     return p;
   }
@@ -410,7 +435,9 @@ struct WideBackend {
     if (rc) return rc;
     const int last_kref = mpc ? first_step + nsteps : kref;
     if (last_kref + d.N > Nt) WFAIL(ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
-    if (mpc && ltv) WFAIL(ALTRO_ERR_UNSUPPORTED, "the device MPC loop needs time-invariant dynamics (per-knot dynamics change every step)");
+    if (mpc && ltv && dyn_step_stride == 0)
+      WFAIL(ALTRO_ERR_UNSUPPORTED, "the device MPC loop over per-knot dynamics needs their table for every step: altro_mpc_set_dynamics_track");
+    if (!dyn_covers(last_kref)) WFAIL(ALTRO_ERR_STATE, "the dynamics track ends before the last step's window");
     hipEvent_t h0, h1;
     WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
@@ -429,7 +456,8 @@ struct WideBackend {
     if (step < 0) WFAIL(ALTRO_ERR_INVALID_ARG, "bad step");
     if (noise && step + 1 > noise_steps) WFAIL(ALTRO_ERR_INVALID_ARG, "step outside the uploaded noise");
     if (step + 1 + d.N > Nt) WFAIL(ALTRO_ERR_INVALID_ARG, "step runs past the end of the track");
-    if (ltv) WFAIL(ALTRO_ERR_UNSUPPORTED, "the device plant step needs time-invariant dynamics");
+    if (ltv && dyn_step_stride == 0) WFAIL(ALTRO_ERR_UNSUPPORTED, "the device plant step over per-knot dynamics needs altro_mpc_set_dynamics_track");
+    if (!dyn_covers(step + 1)) WFAIL(ALTRO_ERR_STATE, "the dynamics track ends before this step's window");
     WCHK(hipSetDevice(device));
     int rc = prepare_launch();
     if (rc) return rc;

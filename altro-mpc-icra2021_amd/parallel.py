@@ -30,3 +30,58 @@ def gather_results(U1, status, device=None):
     dist.all_gather_into_tensor(ug, u)
     dist.all_gather_into_tensor(sg, s)
     return ug.reshape(-1, u.shape[-1]).cpu().numpy(), sg.reshape(-1).cpu().numpy()
+
+
+class RankGroup:
+    """The process-group side of bench.py's timed region, in one place so that the CPU tests run the very
+    code the driver launches on 8 GPUs (there with backend "nccl" = RCCL, in tests/ with "gloo"):
+    one process per GPU started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment); barrier + device synchronise on both sides of the timed region; MAX over ranks
+    of the wall time; SUM over ranks of counters; one all_gather of the results afterwards."""
+
+    def __init__(self, backend="nccl", device=None, rank=None, world=None):
+        import os
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.cuda = backend == "nccl"
+        self.device = device if device is not None else (torch.device("cuda", self.local_rank) if self.cuda else torch.device("cpu"))
+        if self.cuda:
+            torch.cuda.set_device(self.local_rank)
+        self.owns_group = False
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
+            kw = {"device_id": self.device} if self.cuda else {}
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self.owns_group = True
+
+    def barrier(self):
+        """barrier + device synchronise: brackets the timed region on both sides"""
+        if self.world > 1:
+            self.dist.barrier()
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v):
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t)
+        return int(t.item())
+
+    def gather(self, U1, status):
+        return gather_results(U1, status, device=self.device)
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            if self.owns_group:
+                self.dist.destroy_process_group()

@@ -45,18 +45,36 @@ def bytes_solve(n, m, N, p):
                 + (N * n + (N - 1) * m) + 2 * (N - 1) * p + 12)
 
 
-def measured_traffic(batch, steps, spl, world):
+def measured_traffic(batch, steps, warmup, spl, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command; FETCH_SIZE doubled per MI355X_MICROARCH.md and tools/probes/fetch_calib.hip).
-    Only returned when the committed measurement is for exactly this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    t = json.load(open(path))
-    if t.get("batch") == batch and t.get("steps") == steps and t.get("steps_per_launch") == spl and world == 1:
-        return t["hbm_bytes_per_launch"]
-    return None
+    (profiles/rNN_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command line; FETCH_SIZE doubled per MI355X_MICROARCH.md and tools/probes/fetch_calib.hip).
+    Only returned when a committed measurement exists for exactly this configuration: the file holds
+    one entry per profiled command line (the driver's `--steps 20 --warmup 5` and the default)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in (t.get("entries") or [t]):
+            if (e.get("batch") == batch and e.get("steps") == steps and e.get("steps_per_launch") == spl and
+                    e.get("warmup", warmup) == warmup and world == 1):
+                best = e["hbm_bytes_per_launch"]      # later rounds override earlier ones
+    return best
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _cpu_worker(args):
@@ -84,12 +102,18 @@ def _cpu_worker(args):
     return solves, t_solve
 
 
+PUBLISHED_1THREAD_MS = 0.868
+"""the reference's published median of one warm ALTRO MPC solve, random-linear n=12 m=6 N=51, one thread of
+an unnamed CPU (figures/horizon_comp.tikz:11; BASELINE.md): the sanity anchor for the 1-thread figure below"""
+
+
 def cpu_baseline(budget_s=12.0):
     """CPU restatement (the oracle, kind 'port') timed on this host's cores, same workload,
-    same options, one warm-started solve per MPC step (SURVEY 6.2 caveat).  Run BEFORE the GPU
+    same options, one warm-started solve per MPC step (SURVEY 6.2 caveat).  One process per core
+    this job may use (affinity mask and cgroup quota; the count is reported).  Run BEFORE the GPU
     is touched (process pool forks)."""
     import multiprocessing as mp
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = host_cores()
     steps = 40
     per = 1500  # instances offered to each worker; it stops when the time budget is spent
     ctx = mp.get_context("fork")
@@ -103,9 +127,13 @@ def cpu_baseline(budget_s=12.0):
         "value": solves / (t_solve / cores),          # solves/s with all `cores` busy (solve time only)
         "unit": "solves/s",
         "cores": cores,
+        "host_logical_cpus": os.cpu_count(),
         "kind": "port",
         "per_core": solves / t_solve,
         "ms_per_solve_1core": 1e3 * t_solve / solves,
+        "published_ms_per_solve_1thread": PUBLISHED_1THREAD_MS,
+        "published_note": "reference, n=12 m=6 N=51, unnamed CPU, Julia 1.4 (figures/horizon_comp.tikz:11); "
+                          "timed there over repeated solves from converged duals (benchmark_solve!)",
         "sample": f"{solves} warm-started MPC solves (random_linear n=12 m=4 N=50, same options), "
                   f"{cores} processes x whole MPC loops of {steps} steps, {wall:.1f} s wall",
     }
@@ -134,16 +162,14 @@ def main():
         cpu = cpu_baseline()
 
     import torch
-    import torch.distributed as dist
     import altro_amd_loader  # noqa: F401
     import altro_mpc_icra2021_amd as altro
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the solver has no CPU path")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # process-group plumbing of the timed region (tests/test_parallel_gloo.py runs the same class over gloo)
+    grp = altro.parallel.RankGroup("nccl")
+    assert (grp.rank, grp.world) == (rank, world)
 
     B, K, W = a.batch, a.steps, a.warmup
     pb = altro.problems.gen_random_linear_batch(B, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=K + W, seed=1,
@@ -154,13 +180,8 @@ def main():
         mp.step(i)
     altro.timing_reset(mp.solver)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     spl = a.steps_per_launch if a.steps_per_launch > 0 else K
-    barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     i = W
     while i < W + K:
@@ -168,12 +189,8 @@ def main():
         mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
         i += n
     mp.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    grp.barrier()
+    dt = grp.max_over_ranks(time.perf_counter() - t0)
 
     st = altro.stats(mp.solver)
     ms = altro.timing_get(mp.solver)
@@ -185,12 +202,9 @@ def main():
     # final gather of the first controls + status (what an MPC consumer reads each tick): the only
     # collective of the run, after the timed region
     U1 = altro.controls(mp.solver)[:, 0].copy()
-    allU, allS = altro.parallel.gather_results(U1, st.status, device="cuda")
+    allU, allS = grp.gather(U1, st.status)
     assert allU.shape == (world * B, N_CTRL)
-    if world > 1:
-        oks = torch.tensor([ok], device="cuda")
-        dist.all_reduce(oks)
-        ok = int(oks.item())
+    ok = grp.sum_over_ranks(ok)
 
     if rank == 0:
         n, m, N = N_STATE, N_CTRL, N_KNOT
@@ -221,10 +235,12 @@ def main():
                        "options": "tol 1e-4, penalty_initial 1000, penalty_scaling 100, reset_duals=false "
                                   "(run_random_linear.jl:41-49)",
                        "parallelism": "instances sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic(B, K, spl, world),
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic(B, K, W, spl, world),
                          "kernel": "altro::solve_kernel<12,4>", "avg_launch_ms": avg_ms, "launches": int(len(ms)),
-                         "note": "FP64 VALU (v_fmac_f64_dpp) path; MI355X FP64 vector peak = FP64 matrix peak",
+                         "note": "FP64 VALU (v_fmac_f64_dpp) kernel, no MFMA: the compute roof is the FP64 vector peak "
+                                 "(= the FP64 matrix peak on MI355X); traffic = measured HBM bytes per launch "
+                                 "(committed rocprofv3 PMC passes of this command line) or null",
                          "hbm_algorithmic_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
                          "hbm_frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
@@ -237,9 +253,7 @@ def main():
             "rollouts_per_solve": float(nr.sum() / (B * K)),
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -99,6 +99,19 @@ typedef struct altro_opts {
   int32_t reset_penalties;
   int32_t bp_reg;
   int32_t soc_second_order;
+  /* 0 (default): the 16-lane kernels take three shortcuts relative to Altro.jl's forwardpass! / backwardpass!
+   *   - confirmation iterations: when every feedforward term of a backward pass is at rounding level
+   *     (|d| <= 1e-9 (1 + |u|), the case of the last iteration of nearly every warm MPC solve) the rollout,
+   *     line search and gradient sweep of that iteration are skipped and it is booked as converged on the
+   *     trajectory it holds (same status and iteration count; the reference's own result differs from it by
+   *     O(|d|), and whether IT accepts the step or fails the search is decided by the rounding of J);
+   *   - a line search whose alpha = 1 trial moved no element by more than 1e-7 (1 + |z|) while the quadratic
+   *     model promised less than cost_tolerance / 1000 is ended there (the reference halves alpha
+   *     iterations_linesearch more times, fails the same way, and the iteration ends "converged" either way);
+   *   - S is not re-symmetrised after every knot of the backward pass (the asymmetry stays at rounding level).
+   * 1: none of them, the reference's exact sequence (about 40 % slower on BASELINE's headline workload).
+   * The one-wave-per-instance kernel always runs the exact sequence. */
+  int32_t strict;
 } altro_opts;
 
 #define ALTRO_TRACE_LEN 16 /* per-instance trace depth kept on device */
@@ -243,6 +256,19 @@ int32_t altro_mpc_set_noise_model(altro_handle* h, int32_t mode, const double* w
  * shifting them by one knot (flexible_sat_mpc.jl:275-276 leaves both shift_fill! calls commented
  * out); default 1 */
 int32_t altro_mpc_set_shift(altro_handle* h, int32_t shift);
+/* Per-knot (LTV) dynamics for the device-resident MPC loop.  The reference re-linearises its model before
+ * every solve (update_dynamics_matrices!, altro_solver.jl:5-37: model.A[k], B[k], d[k] for the knots of the
+ * new horizon); for a loop that runs on the device the blocks of every step are uploaded once.  Each
+ * instance (or all of them, per_instance = 0) owns `nblocks` knot blocks A [n x n], B [n x m], f [n]
+ * (column-major, f may be NULL); the solve whose reference window starts at knot r -- MPC step i has
+ * r = i + 1, a plain solve before the loop r = 0 -- reads block r * step_stride + k for its knot k:
+ *   step_stride = 1      blocks indexed by absolute knot, like the reference track (a linearisation that
+ *                        depends on time only: gait schedule, planned footholds); nblocks >= steps + N
+ *   step_stride = N - 1  one full table of N - 1 blocks per step (re-linearisation about anything)
+ * The plant step of altro_mpc_step_async uses knot 0 of the window that is current before the step.
+ * Replaces altro_batch_set_dynamics; like it, must be the first call on an (n, m) of the 16-lane set. */
+int32_t altro_mpc_set_dynamics_track(altro_handle* h, const double* A, const double* B, const double* f,
+                                     int32_t nblocks, int32_t step_stride, int32_t per_instance);
 /* One MPC step i (0-based), enqueued on the handle's stream, in the reference's order
  * (random_linear_problem.jl:125-139,161): x0 <- A x_1 + B u_1 + noise_i*||.||_inf/100;
  * reference window <- i+1; primal shift_fill; dual shift_fill; solve. */

@@ -66,12 +66,15 @@ def test_mpc_loop_matches_oracle(oracle, n, m, N):
             assert np.array_equal(X[b, 0], x0g[b])  # :err_x0 of the reference is identically 0
 
 
-@pytest.mark.parametrize("n,m,N", [(12, 6, 31), (2, 2, 21), (15, 2, 21), (35, 2, 21), (55, 2, 21), (30, 10, 21), (30, 25, 21)])
+@pytest.mark.parametrize("n,m,N", [(12, 6, 31), (2, 2, 21), (15, 2, 21), (35, 2, 21), (55, 2, 21), (30, 10, 21), (30, 25, 21),
+                                   (16, 4, 50), (32, 4, 50), (48, 4, 50), (64, 4, 50)])
 def test_mpc_loop_wide_kernel_sizes_match_oracle(oracle, n, m, N):
     """Sizes outside the 16-lane kernel set run on the one-wave-per-instance MFMA kernel
-    (solve_wide.h): the horizon sweep's (12, 6), and points of the state- and control-dimension
-    sweeps (run_random_linear.jl:110-153: n in {2..55} with m = 2, m in {2..25} with n = 30)."""
-    B, S = 5, 4
+    (solve_wide.h): the horizon sweep's (12, 6), points of the state- and control-dimension
+    sweeps (run_random_linear.jl:110-153: n in {2..55} with m = 2, m in {2..25} with n = 30), and
+    BASELINE configs[3]'s own shape (n in {16, 32, 48, 64}, m = 4, N = 50: every LDS size class of
+    the kernel up to its largest, n = 64)."""
+    B, S = (5, 4) if N < 50 else (4, 3)
     pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=21)
     mp = altro.mpc.BatchMPC(pb)
     assert altro.wave_cycles(mp.solver).size == 0        # the 16-lane kernel's diagnostic is absent: wide path
@@ -146,6 +149,215 @@ def test_quadruped_contact_switching_mpc_matches_oracle(oracle, N, lin):
             fz = U[b][:, 2::3]
             nact += int((fz < 1e-3).sum())
     assert nact > 20      # swing legs sit on the f_z >= 0 bound: the contact switches are exercised
+
+
+def _quadruped_track(qp, t0, nblocks):
+    """(A, B, d) of absolute knots 0 .. nblocks-1 for every instance: the trot's contact mask at t0[b] + t dt,
+    linearised about x_des (update_dynamics_matrices!, altro_solver.jl:5-37)"""
+    long = P.gen_quadruped_problem(N=nblocks + 1)
+    D = [long.dynamics(t) for t in t0]
+    return np.stack([a for a, _, _ in D]), np.stack([bm for _, bm, _ in D]), np.stack([dd for _, _, dd in D])
+
+
+def _quadruped_device_loop(qp, x0, A, Bm, d, noise, steps):
+    """TrackMPC over the quadruped problem with the dynamics of every tick resident on the device"""
+    B, N = x0.shape[0], qp.N
+    Nt = steps + N + 1
+    prob = quadruped_gpu_problem(altro, qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
+    mp = altro.mpc.TrackMPC(prob, altro.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
+                            noise, (np.full(12, 1e-3),))
+    altro.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
+    altro.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))      # set_track installed the track's zeros
+    return mp
+
+
+@pytest.mark.parametrize("N", [15, 40])
+def test_quadruped_ltv_mpc_runs_device_resident(oracle, N):
+    """The reference re-linearises the model before every tick (altro_solver.jl:5-37, then :44-88).  With the blocks
+    of every tick uploaded once (altro_mpc_set_dynamics_track) the whole loop -- plant step with the current
+    knot-0 model, new x0, window <- tick + 1, shift_fill, solve -- runs on the device: K ticks in one launch are
+    bit-identical to K single-tick launches, and every tick matches the oracle driven through the reference's
+    sequence with its model rewritten per tick."""
+    B, S = 6, 5
+    qp = P.gen_quadruped_problem(N=N)
+    rng = np.random.default_rng(7)
+    t0 = rng.uniform(0.0, 0.8, B)
+    x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+    A, Bm, d = _quadruped_track(qp, t0, S + N)
+    noise = rng.standard_normal((S, B, 12))
+    one, fused = (_quadruped_device_loop(qp, x0, A, Bm, d, noise, S) for _ in range(2))
+    assert altro.wave_cycles(one.solver).size == 0
+    orcs = [quadruped_oracle(oracle, qp, x0[b], A[b, :N - 1], Bm[b, :N - 1], d[b, :N - 1], P.QUADRUPED_OPTS) for b in range(B)]
+    one.initial_solve()
+    fused.initial_solve()
+    st, X, U = altro.stats(one.solver), altro.states(one.solver), altro.controls(one.solver)
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+    for i in range(S):
+        one.step(i)
+        st, X, U, x0g = altro.stats(one.solver), altro.states(one.solver), altro.controls(one.solver), one.x0()
+        for b, o in enumerate(orcs):
+            xn = o.plant_step() + 1e-3 * noise[i, b]                           # the model of the tick that just ended
+            assert np.abs(xn - x0g[b]).max() <= 1e-12 * max(1.0, np.abs(xn).max())
+            o.set_dynamics(A[b, i + 1:i + N], Bm[b, i + 1:i + N], d[b, i + 1:i + N])
+            o.set_initial_state(xn)
+            o.shift_fill(True, True)
+            check_against_oracle(st, X, U, b, o, o.solve())
+    fused.run_async(S, first=0)
+    fused.synchronize()
+    sf = altro.stats(fused.solver)
+    assert np.array_equal(altro.states(fused.solver), X) and np.array_equal(altro.controls(fused.solver), U)
+    assert np.array_equal(sf.iterations, st.iterations) and np.array_equal(sf.cost, st.cost) and np.array_equal(sf.status, st.status)
+    assert np.array_equal(fused.x0(), x0g)
+
+
+def test_quadruped_full_batch_properties_and_sampled_parity(oracle):
+    """BASELINE configs[4] at its per-GPU size: quadruped contact-switching MPC, N = 40, batch 2048 (16384 over 8
+    GPUs), three ticks device-resident.  The oracle follows a strided sample; the whole batch is checked through
+    size-independent properties: every status SOLVE_SUCCEEDED, 0 <= f_z <= 133 and the friction pyramids to the
+    constraint tolerance, the per-knot affine dynamics satisfied, x_1 == x0 exactly, instance results independent of
+    the batch around them."""
+    B, S, N = 2048, 3, 40
+    qp = P.gen_quadruped_problem(N=N)
+    rng = np.random.default_rng(17)
+    t0 = rng.uniform(0.0, 0.8, B)
+    x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+    # the gait has four phases: linearise once per distinct contact pattern and index it by (instance, knot)
+    A, Bm, d = np.zeros((B, S + N, 12, 12)), np.zeros((B, S + N, 12, 12)), np.zeros((B, S + N, 12))
+    cache = {}
+    for b in range(B):
+        for t in range(S + N):
+            c = tuple(P.trot_contacts(t0[b] + t * qp.dt))
+            if c not in cache:
+                cache[c] = P.quadruped_linearize(qp.x_des, np.zeros(12), qp.feet, np.array(c), qp.inertia, qp.mass, qp.dt)
+            A[b, t], Bm[b, t], d[b, t] = cache[c]
+    noise = rng.standard_normal((S, B, 12))
+    mp = _quadruped_device_loop(qp, x0, A, Bm, d, noise, S)
+    mp.initial_solve()
+    sample = list(range(0, B, 511)) + [B - 1]
+    orcs = {b: quadruped_oracle(oracle, qp, x0[b], A[b, :N - 1], Bm[b, :N - 1], d[b, :N - 1], P.QUADRUPED_OPTS) for b in sample}
+    for o in orcs.values():
+        o.solve()
+    tol = P.QUADRUPED_OPTS["constraint_tolerance"]
+    for i in range(S):
+        mp.step(i)
+        st, X, U, x0g = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()
+        assert np.all(st.status == altro.SOLVE_SUCCEEDED), np.bincount(st.status)
+        assert np.array_equal(X[:, 0], x0g)
+        fx, fy, fz = U[:, :, 0::3], U[:, :, 1::3], U[:, :, 2::3]
+        assert fz.min() >= -tol and fz.max() <= qp.fz_max + tol
+        assert (np.abs(fx) - qp.mu * fz).max() <= tol and (np.abs(fy) - qp.mu * fz).max() <= tol
+        Aw, Bw, dw = A[:, i + 1:i + N], Bm[:, i + 1:i + N], d[:, i + 1:i + N]
+        Xn = np.einsum("bkij,bkj->bki", Aw, X[:, :-1]) + np.einsum("bkij,bkj->bki", Bw, U) + dw
+        assert np.abs(Xn - X[:, 1:]).max() <= 1e-11 * max(1.0, np.abs(X).max())
+        for b, o in orcs.items():
+            xn = o.plant_step() + 1e-3 * noise[i, b]
+            o.set_dynamics(A[b, i + 1:i + N], Bm[b, i + 1:i + N], d[b, i + 1:i + N])
+            o.set_initial_state(xn)
+            o.shift_fill(True, True)
+            check_against_oracle(st, X, U, b, o, o.solve())
+    sub = np.array([5, 1000, B - 1])
+    mp2 = _quadruped_device_loop(qp, x0[sub], A[sub], Bm[sub], d[sub], noise[:, sub], S)
+    mp2.initial_solve()
+    mp2.run_async(S, first=0)
+    mp2.synchronize()
+    assert np.array_equal(altro.states(mp2.solver), X[sub]) and np.array_equal(altro.controls(mp2.solver), U[sub])
+
+
+def test_rocket_full_batch_properties(oracle):
+    """BASELINE configs[2] at its own size: rocket landing with the three second-order cones, N_mpc = 100, batch 4096,
+    fused device loop.  Whole-batch properties after every launch: thrust-magnitude, thrust-angle and glideslope
+    cones to the reported violation, affine dynamics satisfied, x_1 == x0, every solve either SOLVE_SUCCEEDED or
+    stopped at the penalty cap with a violation below 2e-2 (1-11 % of the solves as the loop goes on; the oracle does the same on those inputs: DESIGN.md),
+    reported c_max consistent with the cones evaluated on the host, instances independent of the batch."""
+    B, Nm, S = 4096, 100, 4
+    Nt, dt = 301, 0.05
+    rp = P.gen_rocket_problem(N=Nt, tf=(Nt - 1) * dt, Qfk=1e4, Rk=1.0, theta_thrust_max=5.0, theta_glideslope=45.0)
+    rng = np.random.default_rng(23)
+    x0 = np.tile(rp.x0, (B, 1)) + rng.standard_normal((B, 6)) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
+    cold = altro.ALTROSolver(rocket_gpu_problem(altro, rp, x0), altro.SolverOptions(**ROCKET_COLD_OPTS))
+    altro.solve(cold)
+    assert np.all(altro.stats(cold).status == 1)
+    Xt, Ut = altro.states(cold), altro.controls(cold)
+    cold.close()
+    tp = P.gen_rocket_problem(N=Nm, tf=dt * (Nm - 1), include_goal=False, theta_thrust_max=5.0, theta_glideslope=45.0)
+    tp.Q, tp.R, tp.Qf = np.full(6, 10.0), np.full(3, 0.1), np.full(6, 10.0)
+    noise = rng.standard_normal((S, B, 6))
+    wts, grp = np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])
+
+    def loop(idx):
+        prob = rocket_gpu_problem(altro, tp, Xt[idx, 0].copy(), Xt[idx, :Nm].copy(), Ut[idx, :Nm - 1].copy(), U0=Ut[idx, :Nm - 1].copy())
+        mp = altro.mpc.TrackMPC(prob, altro.SolverOptions(**ROCKET_MPC_OPTS), Xt[idx], Ut[idx], noise[:, idx], (wts, grp))
+        mp.initial_solve()
+        return mp
+
+    mp = loop(np.arange(B))
+    u_bnd, tan_th, tan_gl = 2.0 * 10.0 * 9.81, np.tan(np.deg2rad(5.0)), np.tan(np.deg2rad(45.0))
+    for i in range(S):
+        mp.step(i)
+        st, X, U, x0g = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()
+        ok = st.status == altro.SOLVE_SUCCEEDED
+        assert ok.mean() >= 0.85, ok.mean()
+        assert np.all(st.c_max[ok] < ROCKET_MPC_OPTS["constraint_tolerance"]) and np.all(st.c_max[~ok] < 2e-2)
+        assert np.array_equal(X[:, 0], x0g)
+        Xn = X[:, :-1] @ tp.A.T + U @ tp.Bm.T + tp.f
+        assert np.abs(Xn - X[:, 1:]).max() <= 1e-11 * max(1.0, np.abs(X).max())
+        # cone violations on the host: projection distance <= the |v| - t excess
+        ex = np.maximum(np.linalg.norm(U, axis=2) - u_bnd, 0.0).max(1)
+        ex = np.maximum(ex, np.maximum(np.linalg.norm(U[:, :, :2], axis=2) - tan_th * U[:, :, 2], 0.0).max(1))
+        ex = np.maximum(ex, np.maximum(np.linalg.norm(X[:, 7:Nm - 1, :2], axis=2) - tan_gl * X[:, 7:Nm - 1, 2], 0.0).max(1))
+        assert np.all(ex <= 2.0 * st.c_max + 1e-9), (ex - 2.0 * st.c_max).max()
+    sub = np.array([3, 2000, B - 1])
+    mp2 = loop(sub)
+    mp2.run_async(S, first=0)
+    mp2.synchronize()
+    assert np.array_equal(altro.states(mp2.solver), X[sub]) and np.array_equal(altro.controls(mp2.solver), U[sub])
+
+
+def test_strict_option_matches_oracle_and_bounds_the_default_shortcuts(oracle):
+    """altro_opts.strict = 1 runs Altro.jl's exact sequence on the 16-lane kernels (no line-search early-out,
+    S <- (S + S')/2 after every knot); the default takes both shortcuts (include/altro_batch.h).
+    (a) strict against the oracle: everything check_against_oracle compares plus the accepted steps;
+    (b) default against strict over a 100-step closed loop: same statuses, iteration counts equal in all but a
+        sliver of solves, closed-loop states and applied controls within 1e-6."""
+    B, S = 8, 8
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=12)
+    mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(strict=1, **REF_OPTS))
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    for o in orcs:
+        o.solve()
+    for i in range(S):
+        mp.step(i)
+        st, X, U, at = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), altro.alpha_trace(mp.solver)
+        for b, o in enumerate(orcs):
+            mpc_update(o, pb, b, i)
+            so = o.solve()
+            check_against_oracle(st, X, U, b, o, so)
+            # accepted steps wherever the iteration made progress (at a converged iterate J(alpha) - J is pure
+            # rounding and the two sides may accept different steps for the same trajectory)
+            k = min(so.iterations, at.shape[1])
+            Jt = np.array(so.J[:k])
+            moved = np.r_[True, np.abs(np.diff(Jt)) > 1e-9 * np.maximum(1.0, np.abs(Jt[1:]))]
+            assert np.array_equal(at[b, :k][moved], np.array(so.alpha[:k])[moved]), (i, b, at[b, :k], list(so.alpha[:k]))
+    B, S = 256, 100
+    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=13)
+    runs = []
+    for strict in (0, 1):
+        mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(strict=strict, **REF_OPTS))
+        mp.initial_solve()
+        x0s, u1s, its, sts = [], [], [], []
+        for i in range(S):
+            mp.step(i)
+            st = altro.stats(mp.solver)
+            x0s.append(mp.x0()); u1s.append(altro.controls(mp.solver)[:, 0].copy()); its.append(st.iterations.copy()); sts.append(st.status.copy())
+        runs.append((np.array(x0s), np.array(u1s), np.array(its), np.array(sts), altro.timing_get(mp.solver).sum()))
+    (xa, ua, ia, sa, ta), (xb, ub, ib, sb, tb) = runs
+    assert np.array_equal(sa, sb) and np.all(sa == altro.SOLVE_SUCCEEDED)
+    assert (ia != ib).mean() <= 5e-3, (ia != ib).mean()
+    assert rel_err(xa, xb) <= RTOL and rel_err(ua, ub) <= RTOL, (rel_err(xa, xb), rel_err(ua, ub))
+    print("strict vs default over %d x %d solves: iteration counts differ in %.3f %%, closed-loop x0 %.1e, u1 %.1e; kernel time %.1f vs %.1f ms" % (
+        B, S, 100 * (ia != ib).mean(), rel_err(xa, xb), rel_err(ua, ub), tb, ta))
 
 
 def test_benchmark_solve_protocol_matches_oracle(oracle):

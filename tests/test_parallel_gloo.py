@@ -39,16 +39,27 @@ def solve_shard(first, count):
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    first = altro.parallel.shard_first_instance(rank, B_PER_RANK)
+    """bench.py's timed-region sequence over gloo, through the same RankGroup class bench.py uses on RCCL:
+    init from the torch.distributed.run environment, barrier, work, barrier, MAX of the wall time over
+    ranks, SUM of a counter, the final gather, close."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    grp = altro.parallel.RankGroup("gloo")
+    assert (grp.rank, grp.world) == (rank, world) and dist.is_initialized()
+    first = altro.parallel.shard_first_instance(grp.rank, B_PER_RANK)
+    grp.barrier()
+    t0 = time.perf_counter()
     U1, st = solve_shard(first, B_PER_RANK)
-    allU, allS = altro.parallel.gather_results(U1, st)
-    dist.barrier()
+    if rank == 1:
+        time.sleep(0.3)                      # the slower rank sets the job's time
+    grp.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = grp.max_over_ranks(dt_local if rank == 1 else 0.0)
+    ok = grp.sum_over_ranks(int((st == altro.SOLVE_SUCCEEDED).sum()))
+    allU, allS = grp.gather(U1, st)
     if rank == 0:
-        q.put((allU, allS))
-    dist.destroy_process_group()
+        q.put((allU, allS, dt, ok))
+    grp.close()
+    assert not dist.is_initialized()
 
 
 def test_two_rank_shards_equal_single_batch(oracle):
@@ -67,7 +78,8 @@ def test_two_rank_shards_equal_single_batch(oracle):
         assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
         assert time.time() - t0 < 120, "ranks timed out"
         time.sleep(0.1)
-    allU, allS = q.get()
+    allU, allS, dt, ok = q.get()
+    assert dt >= 0.3 and ok == 2 * B_PER_RANK      # MAX over ranks came from rank 1; the counter was summed
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
