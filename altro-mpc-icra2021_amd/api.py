@@ -388,6 +388,14 @@ def work_counters(solver):
     return tuple(a)
 
 
+def confirm_counter(solver):
+    """iterations per instance (since timing_reset) that the default mode confirmed as converged with the
+    first-order costate sweep instead of a backward pass (altro_batch_get_confirm_counter)."""
+    a = np.zeros(solver.B, dtype=np.int64)
+    solver._chk(solver._L.altro_batch_get_confirm_counter(solver.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+    return a
+
+
 def wave_cycles(solver):
     """(waves, 8) s_memtime ticks of the last solve launch per wave: total, backward, closed
     rollouts, open rollouts, Todorov gradient, dual update (diagnostic)."""

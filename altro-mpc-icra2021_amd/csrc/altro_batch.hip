@@ -36,7 +36,8 @@ struct altro_handle {
   double* Zsave = nullptr;       // [N][Bp][16]: Z0 of altro_batch_benchmark_solve
   hipEvent_t bev0 = nullptr, bev1 = nullptr;
   long long *n_backward = nullptr, *n_rollout = nullptr, *wave_cycles = nullptr;
-  long long *n_solves = nullptr, *n_iters = nullptr, *n_ok = nullptr, *n_trials = nullptr;
+  long long *n_solves = nullptr, *n_iters = nullptr, *n_ok = nullptr, *n_trials = nullptr, *n_gconf = nullptr;
+  int* dzero = nullptr;  // [Bp] the last iteration of the last solve was costate-confirmed: its d is zero
   // problem data (device)
   double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
@@ -329,6 +330,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace; p.atrace = h->atrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
   p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
+  p.n_gconf = h->n_gconf; p.dzero = h->dzero;
   p.o = h->o;
   const dim3 grid(h->Bp / IPW), block(64);
   const int n = h->d.n, m = h->d.m;
@@ -545,6 +547,10 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_trials, Bp * sizeof(long long)));
     CCHK(hipMemsetAsync(h->n_trials, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMalloc(&h->n_gconf, Bp * sizeof(long long)));
+    CCHK(hipMemsetAsync(h->n_gconf, 0, Bp * sizeof(long long), h->stream));
+    CCHK(hipMalloc(&h->dzero, Bp * sizeof(int)));
+    CCHK(hipMemsetAsync(h->dzero, 0, Bp * sizeof(int), h->stream));
     CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
@@ -589,7 +595,7 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
-                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave};
+                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
   h->stage_bytes = 0;
@@ -1116,13 +1122,17 @@ int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
     const size_t n = h->d.n, m = h->d.m, N = h->d.N, B = h->d.batch, Bp = h->Bp;
     std::vector<double> kd((N - 1) * Bp * m * LW);
     HIPCHK(h, hipMemcpy(kd.data(), h->KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // an iteration confirmed by the costate sweep ran no backward pass: K is the previous pass's (the same
+    // matrix: the active set was verified unchanged), its feedforward terms are zero (include/altro_batch.h, strict)
+    std::vector<int> dz(Bp);
+    HIPCHK(h, hipMemcpy(dz.data(), h->dzero, Bp * sizeof(int), hipMemcpyDeviceToHost));
     // device layout [k][instance][control a][lane]: state lane j holds K[a][j], control lane n+a holds d[a]
     for (size_t b = 0; b < B; ++b)
       for (size_t k = 0; k + 1 < N; ++k)
         for (size_t a = 0; a < m; ++a) {
           const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
           if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
-          if (d) d[(b * (N - 1) + k) * m + a] = row[n + a];
+          if (d) d[(b * (N - 1) + k) * m + a] = dz[b] ? 0.0 : row[n + a];
         }
     return ALTRO_OK;
   });
@@ -1153,6 +1163,7 @@ int32_t altro_batch_timing_reset(altro_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->n_iters, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->n_ok, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->n_trials, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_gconf, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ALTRO_OK;
   });
@@ -1195,6 +1206,20 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
     if (backward_passes) HIPCHK(h, hipMemcpy(backward_passes, h->n_backward, B * sizeof(long long), hipMemcpyDeviceToHost));
     if (rollouts) HIPCHK(h, hipMemcpy(rollouts, h->n_rollout, B * sizeof(long long), hipMemcpyDeviceToHost));
     if (trials) HIPCHK(h, hipMemcpy(trials, h->n_trials, B * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
+}
+
+int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed) {
+  return guard(h, [&]() -> int32_t {
+    if (!h || !confirmed) return ALTRO_ERR_INVALID_ARG;
+    if (h->wide) {  // the one-wave-per-instance kernel runs every iteration in full
+      for (int32_t b = 0; b < h->d.batch; ++b) confirmed[b] = 0;
+      return ALTRO_OK;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(confirmed, h->n_gconf, (size_t)h->d.batch * sizeof(long long), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   });
 }

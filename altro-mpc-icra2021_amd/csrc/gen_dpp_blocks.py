@@ -102,6 +102,14 @@ def gen(NX, NU):
         [(f"a{p}", f"acc[{p}]") for p in range(NP)],
         [("z", "z")] + [(f"g{j}", f"grow[{j}]") for j in range(NZ)]))
 
+    # ---- GTS: acc_p += sum_{k in part p} bcast_k(s) * g[k]   ((G' s)[lane]: the costate recursion of the
+    #      gradient-only convergence check, 4 partial sums, k < NX)
+    body = [fmac(f"a{k % NP}", "s", f"g{k}", k) for k in range(NX)]
+    out.append(emit_block(
+        "GTS", f"double (&acc)[{NP}], const double& s, const double (&g)[{NX}]", body,
+        [(f"a{p}", f"acc[{p}]") for p in range(NP)],
+        [("s", "s")] + [(f"g{k}", f"g[{k}]") for k in range(NX)]))
+
     # ---- HC: h[i] += sum_r bcast_i(acol[r]) * y[r],  i < NZ, r < 16   (H += A' (M A), column per lane)
     body = [fmac(f"h{i}", f"c{r}", f"y{r}", i) for r in range(16) for i in range(NZ)]
     out.append(emit_block(

@@ -40,6 +40,12 @@ def flops_forward(n, m, N):
     return (N - 1) * (2 * n**2 + 4 * n * m + 2 * (n + m)) + N * 3 * (n + m)
 
 
+def flops_costate(n, m, N):
+    """first-order costate sweep of a confirmed iteration (include/altro_batch.h, strict): per knot
+    lambda_k = l_x + A' lambda_{k+1}, g_k = l_u + B' lambda_{k+1} and the box terms"""
+    return (N - 1) * (2 * n * (n + m) + 8 * (n + m))
+
+
 def bytes_solve(n, m, N, p):
     return 8 * ((n * n + n * m) + n + (N * n + (N - 1) * m) + (N - 1) * m + 2 * (N - 1) * p
                 + (N * n + (N - 1) * m) + 2 * (N - 1) * p + 12)
@@ -196,6 +202,7 @@ def main():
     ms = altro.timing_get(mp.solver)
     nb, nr, ntr = altro.work_counters(mp.solver)
     nsol, nit, nok = altro.solve_counters(mp.solver)
+    ngc = altro.confirm_counter(mp.solver)
     assert int(nsol.sum()) == B * K, (int(nsol.sum()), B * K)
     ok = int(nok.sum())
 
@@ -213,7 +220,11 @@ def main():
         # roofline of the dominant kernel (solve_kernel): algorithmic flops of one launch =
         # sum over instances of the SURVEY 8(d) formula with the MEASURED pass counts
         # (interpolated line-search trials do no rollout; they are not counted as flops)
-        flops_launch = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N)) / max(1, len(ms))
+        # iterations confirmed by the costate sweep (default mode) ran no backward pass: they are priced at the
+        # sweep's own flops, so `achieved` is the arithmetic the kernel executed, not iterations x flops_backward
+        flops_launch = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N) +
+                        ngc.sum() * flops_costate(n, m, N)) / max(1, len(ms))
+        flops_full = (nit.sum() * flops_backward(n, m, N) + (nit.sum() + B * K) * flops_forward(n, m, N)) / max(1, len(ms))
         avg_ms = float(ms.mean()) if len(ms) else float("nan")
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
         bytes_launch = B * K * bytes_solve(n, m, N, 2 * m) / max(1, len(ms))
@@ -251,6 +262,11 @@ def main():
             "interp_trials_per_solve": float(ntr.sum() / (B * K)),
             "backward_passes_per_solve": float(nb.sum() / (B * K)),
             "rollouts_per_solve": float(nr.sum() / (B * K)),
+            "costate_confirmed_iterations_per_solve": float(ngc.sum() / (B * K)),
+            "equivalent_full_iteration_TFLOPs": flops_full / (avg_ms * 1e-3) / 1e12,
+            "equivalent_note": "iterations x (one backward pass + one rollout) + the initial rollout, i.e. what SURVEY 8(d)'s "
+                               "flops_solve gives for a solver that runs every iteration in full, over the same time: "
+                               "comparable with round 1's roofline.achieved; NOT the roofline figure",
         }
         print(json.dumps(out))
     grp.close()

@@ -99,17 +99,22 @@ typedef struct altro_opts {
   int32_t reset_penalties;
   int32_t bp_reg;
   int32_t soc_second_order;
-  /* 0 (default): the 16-lane kernels take three shortcuts relative to Altro.jl's forwardpass! / backwardpass!
-   *   - confirmation iterations: when every feedforward term of a backward pass is at rounding level
-   *     (|d| <= 1e-9 (1 + |u|), the case of the last iteration of nearly every warm MPC solve) the rollout,
-   *     line search and gradient sweep of that iteration are skipped and it is booked as converged on the
-   *     trajectory it holds (same status and iteration count; the reference's own result differs from it by
-   *     O(|d|), and whether IT accepts the step or fails the search is decided by the rounding of J);
+  /* 0 (default): the 16-lane kernels take these shortcuts relative to Altro.jl's forwardpass! / backwardpass!
+   *   - confirmation iterations.  The last iteration of nearly every warm MPC solve only confirms convergence: the
+   *     problem is quadratic inside an active set, so at the point the previous Newton step reached the backward
+   *     pass returns feedforward terms at rounding level; the reference then rolls out Z + O(|d|), finds
+   *     |dJ| ~ 1e-13 and stops (step accepted, or after iterations_linesearch fruitless halvings, whichever way
+   *     the rounding of J falls).  Such an iteration is booked as converged on the trajectory it holds, with the
+   *     same status and iteration count, when (a) on box-constrained problems, from the second iteration of an
+   *     inner solve on, the first-order costate sweep finds |l_u + B' lambda| <= 0.25e-9 dt R (1 + |u|) at every
+   *     knot (so |d| <= 0.5e-9 (1 + |u|)) and the active set unchanged since the previous backward pass -- no
+   *     backward pass is run, the gains reported are that pass's (the same matrices) with d = 0; or (b) a backward
+   *     pass returns |d| <= 1e-9 (1 + |u|) at every knot -- its rollout, line search and gradient sweep are skipped;
    *   - a line search whose alpha = 1 trial moved no element by more than 1e-7 (1 + |z|) while the quadratic
    *     model promised less than cost_tolerance / 1000 is ended there (the reference halves alpha
    *     iterations_linesearch more times, fails the same way, and the iteration ends "converged" either way);
    *   - S is not re-symmetrised after every knot of the backward pass (the asymmetry stays at rounding level).
-   * 1: none of them, the reference's exact sequence (about 40 % slower on BASELINE's headline workload).
+   * 1: none of them, the reference's exact sequence (about half the throughput on BASELINE's headline workload).
    * The one-wave-per-instance kernel always runs the exact sequence. */
   int32_t strict;
 } altro_opts;
@@ -231,6 +236,10 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
 /* Per instance since the last timing reset: solves run, iLQR iterations, solves that ended
  * SOLVE_SUCCEEDED.  Arrays of `batch` int64; any pointer may be NULL. */
 int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded);
+/* Per instance since the last timing reset: iLQR iterations of the default (non-strict) mode that were confirmed
+ * as converged by the first-order costate sweep instead of a backward pass + rollout (altro_opts.strict).  They
+ * are counted in `iterations` but not in `backward_passes`; bench.py prices them at the sweep's own flops. */
+int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed);
 /* Diagnostic: s_memtime ticks each wave (4 instances) spent in the last solve launch, 8 int64 per
  * wave: total, backward passes, closed-loop rollouts, open-loop rollouts, Todorov gradient,
  * dual update, streaming line-search sweeps, 1 spare.  count = 8 * number of waves. */
