@@ -109,6 +109,7 @@ class LinearConstraint:
     A: np.ndarray
     b: np.ndarray
     equality: bool = False
+    per_instance: bool = False   # A is (B, p, n+m) or (B, nk, p, n+m): every instance of the batch owns its data
 
 
 @dataclass
@@ -118,6 +119,7 @@ class NormConstraint:
     new_constraints.jl:72-120) with their rows written on z."""
     A: np.ndarray
     b: np.ndarray
+    per_instance: bool = False   # as LinearConstraint.per_instance
 
 
 def GoalConstraint(xf, n, m):
@@ -183,15 +185,17 @@ class ALTROSolver:
                 self.con_ids.append(cid.value)
             elif isinstance(con, (LinearConstraint, NormConstraint)):
                 A, b = _c(con.A), _c(con.b)
-                per_knot = A.ndim == 3            # (nk, p, n+m): LinearConstraintTraj / AffineSOCTraj
+                per_inst = bool(getattr(con, "per_instance", False))
+                per_knot = A.ndim == (4 if per_inst else 3)   # (nk, p, n+m): LinearConstraintTraj / AffineSOCTraj
                 assert A.shape[-1] == n + m and A.shape[:-1] == b.shape
-                assert not per_knot or A.shape[0] == last - first + 1
+                assert not per_inst or A.shape[0] == B
+                assert not per_knot or A.shape[-3] == last - first + 1
                 soc = isinstance(con, NormConstraint)
                 kind = _lib.CON_SOC if soc else _lib.CON_LINEAR
                 sense = _lib.SENSE_EQ if (not soc and con.equality) else _lib.SENSE_INEQ
                 cid = C.c_int32(-1)
                 self._chk(L.altro_batch_add_constraint(h, kind, sense, first - 1, last - 1, A.shape[-2],
-                                                       _p(A), _p(b), None, None, int(per_knot), C.byref(cid)))
+                                                       _p(A), _p(b), None, None, int(per_knot) | (2 if per_inst else 0), C.byref(cid)))
                 self.con_ids.append(cid.value)
             else:
                 raise AltroError(_lib.ERR_UNSUPPORTED, f"constraint type {type(con).__name__} is not built yet")

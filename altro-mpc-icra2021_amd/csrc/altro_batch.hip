@@ -59,14 +59,16 @@ struct altro_handle {
   // generic affine constraints packed into 4 quads of 4 constraint rows (see solve_dpp16.h)
   double *Acon = nullptr, *bcon = nullptr, *Lc = nullptr;
   int* cmeta = nullptr;
-  std::vector<double> Acon_h, bcon_h;  // per-knot tables [N][16][16], [N][16]
+  std::vector<double> Acon_h, bcon_h;  // per-knot tables [ninst][N][16][16], [ninst][N][16]; ninst = 1 (shared) or Bp
+  bool con_per_instance = false;
+  size_t acon_elems = 0;               // elements the device table Acon currently holds
   std::vector<int> cmeta_h;            // [N][16][4]
   int ncrows = 0;       // 16 once any generic constraint exists (kernel flag)
   bool con_dirty = false, con_locked = false;  // packing is redone until the first solve
   struct ConBlock {
     int id, kind, sense, k0, k1, p;
-    int per_knot;
-    std::vector<double> A, b;  // A row-major p x nz, one block per knot of the range if per_knot
+    int per_knot, per_instance;
+    std::vector<double> A, b;  // A row-major p x nz blocks: [instance if per_instance][knot of the range if per_knot]
     int lanes[LW];
   };
   std::vector<ConBlock> cons;
@@ -325,7 +327,8 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
   p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu;
-  p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
+  p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta;
+  p.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace; p.atrace = h->atrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
@@ -702,8 +705,14 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const d
 static int pack_constraints(altro_handle* h) {
   if (!h->con_dirty) return ALTRO_OK;
   const int nz = h->d.n + h->d.m, N = h->d.N;
-  std::fill(h->Acon_h.begin(), h->Acon_h.end(), 0.0);
-  std::fill(h->bcon_h.begin(), h->bcon_h.end(), 0.0);
+  // one table per instance as soon as any block carries per-instance data (grasp_mpc_helpers.jl:46-55 mutates each
+  // problem's own per-knot tables); the lane assignment (cmeta) is common to the batch either way
+  h->con_per_instance = false;
+  for (const auto& cb : h->cons) h->con_per_instance = h->con_per_instance || cb.per_instance;
+  const size_t ninst = h->con_per_instance ? (size_t)h->Bp : 1, B = h->d.batch;
+  if (ninst * N * LW * LW * sizeof(double) >= (1ull << 32)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-instance constraint tables of this batch exceed 4 GiB; split the batch");
+  h->Acon_h.assign(ninst * N * LW * LW, 0.0);
+  h->bcon_h.assign(ninst * N * LW, 0.0);
   std::fill(h->cmeta_h.begin(), h->cmeta_h.end(), 0);
   for (size_t e = 0; e < (size_t)N * LW; ++e) h->cmeta_h[4 * e + 2] = -1;
   std::vector<char> used((size_t)N * LW, 0);      // lane taken at knot k
@@ -714,12 +723,17 @@ static int pack_constraints(altro_handle* h) {
   };
   auto place = [&](altro_handle::ConBlock& cb, int r, int lane, int type, int pdim) {
     cb.lanes[r] = lane;
+    const size_t nk = cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1;
     for (int k = cb.k0; k <= cb.k1; ++k) {
-      const size_t blk = cb.per_knot ? (size_t)(k - cb.k0) : 0;
       const size_t e = (size_t)k * LW + lane;
       used[e] = 1;
-      for (int jj = 0; jj < nz; ++jj) h->Acon_h[e * LW + jj] = cb.A[(blk * cb.p + r) * nz + jj];
-      h->bcon_h[e] = cb.b[blk * cb.p + r];
+      for (size_t ib = 0; ib < ninst; ++ib) {
+        const size_t src = ib < B ? ib : B - 1;      // padded slots mirror the last instance
+        const size_t blk = (cb.per_instance ? src * nk : 0) + (cb.per_knot ? (size_t)(k - cb.k0) : 0);
+        const size_t et = ib * N * LW + e;
+        for (int jj = 0; jj < nz; ++jj) h->Acon_h[et * LW + jj] = cb.A[(blk * cb.p + r) * nz + jj];
+        h->bcon_h[et] = cb.b[blk * cb.p + r];
+      }
       h->cmeta_h[4 * e + 0] = type;
       h->cmeta_h[4 * e + 1] = cb.k0;
       h->cmeta_h[4 * e + 2] = cb.k1;
@@ -760,6 +774,15 @@ static int pack_constraints(altro_handle* h) {
       for (int i = 0; i < 4; ++i) h->cmeta_h[4 * ((size_t)k * LW + 4 * q + i) + 3] = pdim;
     }
   h->ncrows = h->cons.empty() ? 0 : LW;
+  if (h->Acon_h.size() != h->acon_elems) {  // the table changed shape (per-instance data arrived): reallocate
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->Acon) HIPCHK(h, hipFree(h->Acon));
+    if (h->bcon) HIPCHK(h, hipFree(h->bcon));
+    h->Acon = h->bcon = nullptr;
+    HIPCHK(h, hipMalloc(&h->Acon, h->Acon_h.size() * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->bcon, h->bcon_h.size() * sizeof(double)));
+    h->acon_elems = h->Acon_h.size();
+  }
   HIPCHK(h, hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -784,8 +807,9 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
       if (h->con_locked) FAIL(h, ALTRO_ERR_STATE, "constraints must be added before the first solve");
       altro_handle::ConBlock cb;
       cb.id = h->ncon; cb.kind = kind; cb.sense = sense; cb.k0 = k_first; cb.k1 = k_last; cb.p = p;
-      cb.per_knot = per_knot ? 1 : 0;
-      const size_t nblk = per_knot ? (size_t)(k_last - k_first + 1) : 1;
+      cb.per_knot = (per_knot & 1) ? 1 : 0;
+      cb.per_instance = (per_knot & 2) ? 1 : 0;
+      const size_t nblk = (cb.per_knot ? (size_t)(k_last - k_first + 1) : 1) * (cb.per_instance ? (size_t)h->d.batch : 1);
       cb.A.assign(A, A + nblk * p * nz);
       cb.b.assign(b, b + nblk * p);
       for (int r = 0; r < LW; ++r) cb.lanes[r] = -1;
@@ -834,7 +858,7 @@ int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, cons
     const int nz = h->d.n + h->d.m;
     for (auto& cb : h->cons) {
       if (cb.id != con_id) continue;
-      const size_t nblk = cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1;
+      const size_t nblk = (cb.per_knot ? (size_t)(cb.k1 - cb.k0 + 1) : 1) * (cb.per_instance ? (size_t)h->d.batch : 1);
       if (A) cb.A.assign(A, A + nblk * cb.p * nz);
       if (b) cb.b.assign(b, b + nblk * cb.p);
       // same lanes, new coefficients: refresh the tables (the solver sees it at the next solve, as

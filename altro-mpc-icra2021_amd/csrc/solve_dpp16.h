@@ -48,6 +48,9 @@
 #ifndef ALTRO_PD_CLOSED
 #define ALTRO_PD_CLOSED 4  // knots of prefetch in the closed-loop rollout (2..8 measured with the butterfly gain sums: 4 best)
 #endif
+#ifndef ALTRO_PD_ADJOINT
+#define ALTRO_PD_ADJOINT 4  // knots of prefetch in the costate sweep (12 measured: slower)
+#endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
 #endif
@@ -108,6 +111,7 @@ struct SolveParams {
   // constraints whose knot ranges do not overlap):
   const double* Acon;    // [N][16][16] row-major: value_r = sum_j Acon[k][r][j] z_j + bcon[k][r]
   const double* bcon;    // [N][16]
+  unsigned con_istride;  // 0: Acon / bcon are shared by the batch; N*16*16: one table per instance ([Bp][N][16][16], [Bp][N][16])
   const int* cmeta;      // [N][16][4] per lane: type (0 none, 1 EQ, 2 INEQ, 3 SOC), k0, k1 of the row's
                          // constraint, p (dimension of the cone this lane's quad holds at this knot;
                          // linear rows may use the quad's spare lanes)
@@ -401,13 +405,13 @@ struct Solver {
   // row j of the knot's A (coefficients of z_0..z_NZ-1) for value = A z + b
   __device__ __forceinline__ void con_load(int k, ConK& c) const {
     c.cm = con_meta(k);
-    const unsigned b = ((unsigned)k * LW + j) * LW;
+    const unsigned b = (unsigned)inst * P.con_istride + ((unsigned)k * LW + j) * LW;
     sfor<0, NZ>([&](auto q) { c.arow[decltype(q)::value] = ldg(P.Acon, b + decltype(q)::value); });
-    c.brow = ldg(P.bcon, (unsigned)k * LW + j);
+    c.brow = ldg(P.bcon, (unsigned)inst * (P.con_istride / LW) + (unsigned)k * LW + j);
   }
   // column j of the knot's A (coefficient of z_j in every constraint row)
   __device__ __forceinline__ void con_col(int k, double (&acol)[16]) const {
-    const unsigned b = (unsigned)k * LW * LW + j;
+    const unsigned b = (unsigned)inst * P.con_istride + (unsigned)k * LW * LW + j;
     sfor<0, 16>([&](auto r) { acol[decltype(r)::value] = ldg(P.Acon, b + decltype(r)::value * LW); });
   }
   // constraint values of this lane's row for the knot vector z (one element per lane)
@@ -1145,7 +1149,9 @@ struct Solver {
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, hash);
       sv = is_x ? qz : 0.0;
     }
-    constexpr int PD = 4;  // knots requested ahead (the chain through sv is ~12 dependent FMAs per knot)
+    // knots requested ahead: a knot of this sweep is only ~150 cycles of dependent work (the chain through sv),
+    // so an HBM round trip spans a dozen of them; with 4 the sweep ran at 1.3 k cycles per knot, waiting
+    constexpr int PD = ALTRO_PD_ADJOINT;
     double rz[PD], rzr[PD], rhi[PD], rlo[PD];
     sfor<0, PD>([&](auto u) {
       constexpr int U = decltype(u)::value;

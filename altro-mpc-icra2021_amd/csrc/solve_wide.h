@@ -36,6 +36,8 @@ struct Params {
   int box_k0, box_k1;
   const double* AconT;  // [N][n+m][Pn]: row r of knot k's table is column r
   const double* bcon;   // [N][Pn]
+  size_t con_istride;   // 0: the tables are shared by all instances; N*(n+m)*Pn: one table per instance
+  size_t bcon_istride;  // 0 or N*Pn
   const int* ctype;     // [N][Pn]: 0 none, 1 equality, 2 inequality, 3 row of a second-order cone
   const int *rowk0, *rowk1;  // [Pn] knot range of the constraint block that owns row r
   const int *rowc0, *rowcp;  // [Pn] second-order cones: first row and dimension (2..4) of the cone that owns row r, 0 if none
@@ -226,6 +228,7 @@ struct Solver {
     }
   }
   double *Xi, *Ui, *Lbi, *Lci, *Kgi, *dgi, *x0i;
+  const double *AconTi, *bconi;  // this instance's constraint tables (the shared ones unless per-instance data was given)
   const double *Xri, *Uri;
   int cur, kref;
   double mu, rho, drho;
@@ -254,6 +257,8 @@ struct Solver {
     Lbi = P.Lb + b * N * 2 * nz; Lci = P.Lc + b * N * (Pn > 0 ? Pn : 1);
     Kgi = P.Kg + b * (N - 1) * n * m; dgi = P.dg + b * (N - 1) * m;
     x0i = P.x0 + b * n;
+    AconTi = P.AconT + b * P.con_istride;
+    bconi = P.bcon + b * P.bcon_istride;
     Xri = P.Xref + b * P.Nt * n; Uri = P.Uref + b * (P.Nt - 1) * m;
     for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
     if (T < n) { cwx = P.wd[T]; cwfx = P.wf[T]; cxmax = P.zmax[T]; cxmin = P.zmin[T]; }
@@ -334,9 +339,9 @@ struct Solver {
 
   // value of generic row r at knot k from zb (padded layout: x at [0,n), u at [np, np+m))
   __device__ __forceinline__ double row_value(int k, int r, bool term) const {
-    double v = P.bcon[(size_t)k * Pn + r];
+    double v = bconi[(size_t)k * Pn + r];
     if ((P.con_static & 2) && !term) return dot_lds(Ac + r * ly.ldg, 1, zb, 1, nzp, v);  // table resident in LDS
-    const double* At = P.AconT + (size_t)k * nz * Pn + r;
+    const double* At = AconTi + (size_t)k * nz * Pn + r;
     v = dot_strided(At, Pn, zb, n, v);
     if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
     return v;
@@ -349,7 +354,7 @@ struct Solver {
     for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
       const int j = w.q, r = w.r;
       const int c = j < n ? j : np + (j - n);
-      Ac[r * ly.ldg + c] = P.AconT[((size_t)P.rowk0[r] * nz + j) * Pn + r];
+      Ac[r * ly.ldg + c] = AconTi[((size_t)P.rowk0[r] * nz + j) * Pn + r];
     }
   }
 
@@ -533,7 +538,7 @@ struct Solver {
     if (T < Pn) {
       d.ct = P.ctype[(size_t)k * Pn + T];
       d.lam = Lci[(size_t)k * Pn + T];
-      d.bc = P.bcon[(size_t)k * Pn + T];
+      d.bc = bconi[(size_t)k * Pn + T];
     }
     return d;
   }
@@ -548,7 +553,7 @@ struct Solver {
       if ((P.con_static & 1) && !term) {
         v = dot_lds(Ac + T * ly.ldg, 1, zb, 1, nzp, d.bc);
       } else {
-        const double* At = P.AconT + (size_t)k * nz * Pn + T;
+        const double* At = AconTi + (size_t)k * nz * Pn + T;
         v = dot_strided(At, Pn, zb, n, d.bc);
         if (!term) v = dot_strided(At + (size_t)n * Pn, Pn, zb + np, m, v);
       }
@@ -820,7 +825,7 @@ struct Solver {
         }
         wsync();
       }
-      const double* At = P.AconT + (size_t)k * nz * Pn;
+      const double* At = AconTi + (size_t)k * nz * Pn;
       const bool resident = (P.con_static & 4) && !term;
       Walk w = start(by_P);
       for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {

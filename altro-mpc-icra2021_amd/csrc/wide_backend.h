@@ -72,11 +72,13 @@ struct WideBackend {
   struct Block {
     int id, sense, k0, k1, p, per_knot, r0;
     bool soc = false;
-    std::vector<double> A, b;  // row-major p x nz blocks
+    bool per_instance = false;
+    std::vector<double> A, b;  // row-major p x nz blocks: [instance if per_instance][knot of the range if per_knot]
   };
   std::vector<Block> blocks;
   int Pn = 0, ncon = 0, ncone = 0;
-  bool con_dirty = false, con_locked = false;
+  bool con_dirty = false, con_locked = false, con_per_instance = false;
+  size_t acon_elems = (size_t)-1;
 
   int np() const { return pad16(d.n); }
   int mp() const { return pad16(d.m); }
@@ -230,8 +232,9 @@ struct WideBackend {
     Block bl;
     bl.id = ncon++;
     bl.soc = kind == ALTRO_CON_SOC;
-    bl.sense = sense; bl.k0 = k_first; bl.k1 = k_last; bl.p = p; bl.per_knot = per_knot ? 1 : 0; bl.r0 = Pn;
-    const size_t nb = per_knot ? (size_t)(k_last - k_first + 1) : 1;
+    bl.sense = sense; bl.k0 = k_first; bl.k1 = k_last; bl.p = p; bl.per_knot = (per_knot & 1) ? 1 : 0; bl.r0 = Pn;
+    bl.per_instance = (per_knot & 2) != 0;
+    const size_t nb = (bl.per_knot ? (size_t)(k_last - k_first + 1) : 1) * (bl.per_instance ? (size_t)d.batch : 1);
     bl.A.assign(A_, A_ + nb * p * nz());
     bl.b.assign(b_, b_ + nb * p);
     blocks.push_back(bl);
@@ -250,7 +253,7 @@ struct WideBackend {
   int update_constraint_data(int con_id, const double* A_, const double* b_) {
     Block* bl = find(con_id);
     if (!bl) WFAIL(ALTRO_ERR_INVALID_ARG, "no such LINEAR constraint");
-    const size_t nb = bl->per_knot ? (size_t)(bl->k1 - bl->k0 + 1) : 1;
+    const size_t nb = (bl->per_knot ? (size_t)(bl->k1 - bl->k0 + 1) : 1) * (bl->per_instance ? (size_t)d.batch : 1);
     if (A_) bl->A.assign(A_, A_ + nb * bl->p * nz());
     if (b_) bl->b.assign(b_, b_ + nb * bl->p);
     con_dirty = true;
@@ -262,7 +265,12 @@ struct WideBackend {
     if (!con_dirty) return ALTRO_OK;
     WCHK(hipSetDevice(device));
     const size_t N = d.N, z = nz(), P = Pn;
-    std::vector<double> At(N * z * P, 0.0), bc(N * P, 0.0);
+    // one table per instance as soon as any block carries per-instance data (grasp_mpc_helpers.jl:46-55 mutates each
+    // problem's own tables); otherwise one table shared by the batch
+    con_per_instance = false;
+    for (const auto& bl : blocks) con_per_instance = con_per_instance || bl.per_instance;
+    const size_t ninst = con_per_instance ? (size_t)d.batch : 1;
+    std::vector<double> At(ninst * N * z * P, 0.0), bc(ninst * N * P, 0.0);
     std::vector<int> ct(N * P, 0), k0(P, 0), k1(P, -1), c0(P, 0), cp(P, 0);
     ncone = 0;
     for (const auto& bl : blocks) ncone += bl.soc ? 1 : 0;
@@ -273,20 +281,28 @@ struct WideBackend {
         k1[row] = bl.k1;
         c0[row] = bl.soc ? bl.r0 : 0;
         cp[row] = bl.soc ? bl.p : 0;
+        const size_t nk = bl.per_knot ? (size_t)(bl.k1 - bl.k0 + 1) : 1;
         for (int k = bl.k0; k <= bl.k1; ++k) {
-          const size_t blk = bl.per_knot ? (size_t)(k - bl.k0) : 0;
           ct[k * P + row] = bl.soc ? 3 : (bl.sense == ALTRO_SENSE_EQ ? 1 : 2);
-          bc[k * P + row] = bl.b[blk * bl.p + r];
-          for (size_t j = 0; j < z; ++j) At[(k * z + j) * P + row] = bl.A[(blk * bl.p + r) * z + j];
+          for (size_t ib = 0; ib < ninst; ++ib) {
+            const size_t blk = (bl.per_instance ? ib * nk : 0) + (bl.per_knot ? (size_t)(k - bl.k0) : 0);
+            bc[(ib * N + k) * P + row] = bl.b[blk * bl.p + r];
+            for (size_t j = 0; j < z; ++j) At[((ib * N + k) * z + j) * P + row] = bl.A[(blk * bl.p + r) * z + j];
+          }
         }
       }
+    if (At.size() != acon_elems) {  // the table changed shape (a block with per-instance data arrived): reallocate
+      for (double** p : {&AconT, &bcon})
+        if (*p) { WCHK(hipFree(*p)); *p = nullptr; }
+      WCHK(hipMalloc(&AconT, (At.size() ? At.size() : 1) * sizeof(double)));
+      WCHK(hipMalloc(&bcon, (bc.size() ? bc.size() : 1) * sizeof(double)));
+      acon_elems = At.size();
+    }
     if (!con_locked) {
-      for (void* p : {(void*)AconT, (void*)bcon, (void*)ctype, (void*)rowk0, (void*)rowk1, (void*)rowc0, (void*)rowcp, (void*)Lc})
+      for (void* p : {(void*)ctype, (void*)rowk0, (void*)rowk1, (void*)rowc0, (void*)rowcp, (void*)Lc})
         if (p) WCHK(hipFree(p));
-      AconT = bcon = Lc = nullptr;
+      Lc = nullptr;
       ctype = rowk0 = rowk1 = rowc0 = rowcp = nullptr;
-      WCHK(hipMalloc(&AconT, At.size() * sizeof(double)));
-      WCHK(hipMalloc(&bcon, bc.size() * sizeof(double)));
       WCHK(hipMalloc(&ctype, ct.size() * sizeof(int)));
       WCHK(hipMalloc(&rowk0, P * sizeof(int)));
       WCHK(hipMalloc(&rowk1, P * sizeof(int)));
@@ -389,7 +405,9 @@ struct WideBackend {
     p.ltv = ltv; p.dyn_per_instance = dyn_per_instance;
     p.A = A; p.Bm = Bm; p.f = f; p.wd = wd; p.wf = wf; p.zmin = zmin; p.zmax = zmax;
     p.box_k0 = box_k0; p.box_k1 = box_k1;
-    p.AconT = AconT; p.bcon = bcon; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1; p.rowc0 = rowc0; p.rowcp = rowcp; p.ncone = ncone;
+    p.AconT = AconT; p.bcon = bcon;
+    p.con_istride = con_per_instance ? (size_t)d.N * nz() * Pn : 0;
+    p.bcon_istride = con_per_instance ? (size_t)d.N * Pn : 0; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1; p.rowc0 = rowc0; p.rowcp = rowcp; p.ncone = ncone;
     p.con_static = 7;
     for (const auto& bl : blocks) p.con_static = bl.per_knot ? 0 : p.con_static;
     if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) p.con_static &= atoi(e);  // diagnostic switch

@@ -145,6 +145,102 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
+def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None):
+    """Run W warm-up + K timed MPC steps (one fused launch) of a secondary BASELINE config on one GPU and build
+    its JSON line: same metric, roofline from HIP events on the library's stream and the measured pass counts."""
+    import torch
+    for i in range(W):
+        mp.step(i)
+    altro.timing_reset(mp.solver)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mp.run_async(K, first=W)
+    mp.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = altro.timing_get(mp.solver)
+    nb, nr, ntr = altro.work_counters(mp.solver)
+    nsol, nit, nok = altro.solve_counters(mp.solver)
+    ngc = altro.confirm_counter(mp.solver)
+    flops = nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N) + ngc.sum() * flops_costate(n, m, N)
+    avg_ms = float(ms.mean())
+    achieved = flops / len(ms) / (avg_ms * 1e-3) / 1e12
+    out = {"metric": "MPC solves/sec (batched iLQR to tol), " + name, "value": B * K / dt, "unit": "solves/s", "n_gpus": 1,
+           "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B},
+           "roofline": {"bound": bound, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": None, "kernel": kernel, "avg_launch_ms": avg_ms, "launches": int(len(ms)),
+                        "note": "algorithmic flops of the base Riccati / rollout formulas (SURVEY 8d) with the measured pass counts; "
+                                "constraint-expansion flops are not counted"},
+           "cpu_baseline": None, "solve_succeeded_frac": float(nok.sum() / max(1, nsol.sum())),
+           "iterations_mean": float(nit.sum() / max(1, nsol.sum())), "backward_passes_per_solve": float(nb.sum() / (B * K)),
+           "rollouts_per_solve": float(nr.sum() / (B * K))}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def secondary_configs(which, K, W):
+    """BASELINE configs[2..4] on ONE GPU at their per-GPU sizes (not the headline line; `--config` only)."""
+    import altro_amd_loader  # noqa: F401
+    import altro_mpc_icra2021_amd as altro
+    P, api, mpcm = altro.problems, altro, altro.mpc
+    if which in ("rocket", "all"):   # configs[2]: rocket landing, second-order cones, N_mpc = 100, batch 4096
+        B, Nm, Nt, dt = 4096, 100, 301, 0.05
+        K2 = min(K, Nt - Nm - 1 - W)
+        rp = P.gen_rocket_problem(N=Nt, tf=(Nt - 1) * dt, Qfk=1e4, Rk=1.0, theta_thrust_max=5.0, theta_glideslope=45.0)
+        rng = np.random.default_rng(1)
+        x0 = np.tile(rp.x0, (B, 1)) + rng.standard_normal((B, 6)) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
+        cold = api.ALTROSolver(mpcm.constrained_problem(rp, x0), api.SolverOptions(**altro.benchmarks.ROCKET_COLD_OPTS))
+        api.solve(cold)
+        Xt, Ut = api.states(cold), api.controls(cold)
+        cold.close()
+        tp = P.gen_rocket_problem(N=Nm, tf=dt * (Nm - 1), include_goal=False, theta_thrust_max=5.0, theta_glideslope=45.0)
+        tp.Q, tp.R, tp.Qf = np.full(6, 10.0), np.full(3, 0.1), np.full(6, 10.0)
+        prob = mpcm.constrained_problem(tp, Xt[:, 0].copy(), Xt[:, :Nm].copy(), Ut[:, :Nm - 1].copy(), U0=Ut[:, :Nm - 1].copy())
+        mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, rng.standard_normal((W + K2, B, 6)),
+                           (np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])))
+        mp.initial_solve()
+        _secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
+                        "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro)
+    if which in ("state_dim", "all"):   # configs[3]: state-dimension sweep, m = 4, N = 50, 8192 instances per GPU
+        for n in (8, 16, 32, 48, 64):
+            B = 8192 if n <= 32 else 2048
+            K3 = min(K, 10 if n <= 16 else 5)
+            pb = P.gen_random_linear_batch(B, n=n, m=4, N=50, steps=K3 + W, seed=10)
+            mp = mpcm.BatchMPC(pb)
+            mp.initial_solve()
+            kern = "altro::solve_kernel<8,4>" if n == 8 else "altro_wide::wide_kernel<4>"
+            _secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
+                            kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro)
+            mp.solver.close()
+    if which in ("quadruped", "all"):   # configs[4]: quadruped contact-switching MPC, N = 40, 2048 instances per GPU, LTV loop on device
+        B, N = 2048, 40
+        K4 = min(K, 20)
+        qp = P.gen_quadruped_problem(N=N)
+        rng = np.random.default_rng(17)
+        t0 = rng.uniform(0.0, 0.8, B)
+        x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+        T = W + K4 + N
+        A, Bm, d = np.zeros((B, T, 12, 12)), np.zeros((B, T, 12, 12)), np.zeros((B, T, 12))
+        cache = {}
+        for b in range(B):
+            for t in range(T):
+                c = tuple(P.trot_contacts(t0[b] + t * qp.dt))
+                if c not in cache:
+                    cache[c] = P.quadruped_linearize(qp.x_des, np.zeros(12), qp.feet, np.array(c), qp.inertia, qp.mass, qp.dt)
+                A[b, t], Bm[b, t], d[b, t] = cache[c]
+        Nt = W + K4 + N + 1
+        prob = mpcm.quadruped_problem(qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
+        mp = mpcm.TrackMPC(prob, api.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
+                           rng.standard_normal((W + K4, B, 12)), (np.full(12, 1e-3),))
+        api.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
+        api.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))
+        mp.initial_solve()
+        _secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
+                        "altro_wide::wide_kernel<12>", "mfma", 12, 12, N, B, K4, W, mp, altro)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +248,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="headline", choices=["headline", "rocket", "state_dim", "quadruped", "all"],
+                    help="headline (BASELINE configs[1], the driver's line) or a secondary config: extra JSON lines, 1 GPU only")
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="MPC steps per kernel launch in the timed region (0 = all K in one launch)")
     a = ap.parse_args()
@@ -162,6 +260,12 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+
+    if a.config != "headline":
+        if world != 1:
+            sys.exit("secondary configs are single-GPU lines")
+        secondary_configs(a.config, a.steps, a.warmup)
+        return
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -153,8 +153,12 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qdiag, cons
  *   BOX:    zmin, zmax of length n+m (+-inf = absent)
  *   LINEAR: A [p][n+m] ROW-major, b [p]; value A z + b {= 0 | <= 0}
  *   SOC:    A, b as above; value v = A z + b with ||v[0..p-2]|| <= v[p-1]
- *   per_knot != 0: A, b hold one block per knot of the range (grasp_problem.jl:35-67)
- * Constraint data is shared by all instances of the batch.  HIP library limits: one BOX; cones of
+ *   per_knot: bit 0 set: A, b hold one block per knot of the range (grasp_problem.jl:35-67);
+ *             bit 1 set (values 2, 3): A, b hold those blocks once PER INSTANCE ([batch][knots][p][n+m] and
+ *             [batch][knots][p]): every problem of the batch owns its tables, as the reference's problems do
+ *             when mpc_update! rewrites them in place (grasp_mpc_helpers.jl:46-55) -- instances may then sit at
+ *             different MPC steps or footholds.  The structure (kind, sense, knot range, p) stays common.
+ * Without bit 1 the data is shared by all instances of the batch.  HIP library limits: one BOX; cones of
  * dimension 2..4; on the 16-lane kernels ((n,m) in (12,4) (12,3) (8,4) (6,6) (6,3)) at most
  * 16 LINEAR / SOC rows are active at any one knot (a cone of dimension 2..4 takes the first lanes
  * of an aligned group of 4, linear rows take any free lane; constraints with disjoint knot
@@ -164,7 +168,8 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
                                    int32_t k_last, int32_t p, const double* A, const double* b,
                                    const double* zmin, const double* zmax, int32_t per_knot,
                                    int32_t* con_id);
-/* in-place mutation of per-knot constraint data: grasp_mpc_helpers.jl:46-55 */
+/* in-place mutation of per-knot constraint data: grasp_mpc_helpers.jl:46-55.  A, b in the layout the
+ * constraint was added with (per instance if it was); either may be NULL (unchanged). */
 int32_t altro_batch_update_constraint_data(altro_handle* h, int32_t con_id, const double* A,
                                            const double* b);
 

@@ -931,6 +931,86 @@ def test_grasp_mpc_loop_with_per_step_constraint_updates_matches_oracle(oracle):
             check_against_oracle(st, X, U, b, orcs[b], so)
 
 
+@pytest.mark.parametrize("force_wide", [False, True])
+def test_per_instance_constraint_data_grasp_batch_at_different_mpc_phases(oracle, monkeypatch, force_wide):
+    """Every problem of the reference owns its constraint tables and mpc_update! rewrites them in place
+    (grasp_mpc_helpers.jl:46-55), so a batch may hold problems at DIFFERENT phases of the grasp trajectory.
+    Constraints added with per-instance data (per_knot bits 0 and 1): instance b tracks the window that starts
+    at knot 3 b + i at MPC step i, with its own torque-balance, normal-force and friction-cone tables; each
+    instance against its own oracle, on the 16-lane kernel and on the one-wave-per-instance kernel."""
+    if force_wide:
+        monkeypatch.setenv("ALTRO_FORCE_WIDE", "1")
+    B, Nc, Nm, S = 5, 61, 21, 3
+    gp = P.gen_grasp_problem(N=Nc, tf=6.0)
+    cold = rocket_oracle(oracle, gp, gp.x0, dict(cost_tolerance=1e-6, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-6,
+                                                 iterations=5000, iterations_outer=60, iterations_inner=300))
+    assert cold.solve().status == 1
+    Xt, Ut = cold.states(), cold.controls()
+    mpc_opts = dict(cost_tolerance=1e-4, cost_tolerance_intermediate=1e-3, constraint_tolerance=1e-4,
+                    penalty_initial=10000.0, penalty_scaling=100.0)
+    off = 3 * np.arange(B)                                      # phase of each instance along the cold trajectory
+
+    def window(k0):
+        return [P.ConstraintSpec(c.kind, c.sense, 0, Nm - 2, A=c.A[k0:k0 + Nm - 1].copy(), b=c.b[k0:k0 + Nm - 1].copy())
+                for c in gp.constraints[1:]]
+
+    def batch_tables(i):                                        # per constraint: A (B, Nm-1, p, nz), b (B, Nm-1, p)
+        ws = [window(off[b] + i) for b in range(B)]
+        return [(np.stack([w[ci].A for w in ws]), np.stack([w[ci].b for w in ws])) for ci in range(4)]
+
+    import copy
+    tp = copy.copy(gp)
+    tp.N, tp.Q, tp.R, tp.Qf = Nm, np.full(6, 1e3), np.full(6, 1.0), np.full(6, 10.0)
+    x0 = np.stack([Xt[off[b]] for b in range(B)])
+    Xr = np.stack([Xt[off[b]:off[b] + Nm] for b in range(B)])
+    Ur = np.stack([Ut[off[b]:off[b] + Nm - 1] for b in range(B)])
+    cons = altro.ConstraintList(6, 6, Nm)
+    specs = window(0)
+    for ci, (A, b) in enumerate(batch_tables(0)):
+        c = specs[ci]
+        con = altro.NormConstraint(A, b, per_instance=True) if c.kind == P.SOC else altro.LinearConstraint(A, b, equality=(c.sense == P.EQ), per_instance=True)
+        cons.add_constraint(con, (1, Nm - 1))
+    prob = altro.Problem(altro.LinearModel(tp.A, tp.Bm, tp.f, dt=tp.dt), altro.TrackingObjective(tp.Q, tp.R, tp.Qf, Xr, Ur), cons,
+                         x0=x0, N=Nm, U0=Ur.copy())
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**mpc_opts))
+    assert (altro.wave_cycles(sv).size == 0) == force_wide
+    altro.solve(sv)
+    orcs = []
+    for b in range(B):
+        tb = copy.copy(tp)
+        tb.constraints = window(off[b])
+        orcs.append(rocket_oracle(oracle, tb, x0[b], mpc_opts, Xr[b], Ur[b], U0=Ur[b]))
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    for b in range(B):
+        check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+    assert len({tuple(np.round(U[b, 0], 6)) for b in range(B)}) == B      # the instances really solve different problems
+    rng = np.random.default_rng(31)
+    for i in range(1, S + 1):
+        x0n = np.zeros((B, 6))
+        for b in range(B):
+            xn = orcs[b].plant_step()
+            x0n[b] = xn + rng.standard_normal(6) * np.abs(xn).max() / 100.0
+            orcs[b].set_initial_state(x0n[b])
+            orcs[b].set_reference(Xt[off[b] + i:off[b] + i + Nm], Ut[off[b] + i:off[b] + i + Nm - 1])
+            orcs[b].shift_fill(True, False)
+            for ci, c in enumerate(window(off[b] + i)):
+                orcs[b].update_constraint_data(orcs[b].con_ids[ci], c.A, c.b)
+            orcs[b].shift_fill(False, True)
+        altro.set_initial_state(sv, x0n)
+        altro.update_trajectory(sv, np.stack([Xt[off[b] + i:off[b] + i + Nm] for b in range(B)]),
+                                np.stack([Ut[off[b] + i:off[b] + i + Nm - 1] for b in range(B)]))
+        altro.shift_fill(sv, True, False)
+        for ci, (A, bb) in enumerate(batch_tables(i)):
+            altro.update_constraint_data(sv, ci, A, bb)
+        altro.shift_fill(sv, False, True)
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            so = orcs[b].solve()
+            assert so.status == 1
+            check_against_oracle(st, X, U, b, orcs[b], so)
+
+
 def test_update_constraint_data_is_seen_by_the_next_solve(oracle):
     """grasp_mpc_helpers.jl:46-55 mutates the per-knot constraint matrices in place between
     solves; altro_batch_update_constraint_data is that mutation."""

@@ -5,7 +5,8 @@ sys.path.insert(0, R)
 import numpy as np
 import altro_amd_loader
 import altro_mpc_icra2021_amd as altro
-B, S = 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 100
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 pb = altro.problems.gen_random_linear_batch(B, steps=S + 5)
 mp = altro.mpc.BatchMPC(pb)
 mp.initial_solve()
@@ -20,6 +21,12 @@ print("wave cycles: mean %.2fM  p50 %.2fM  p99 %.2fM  max %.2fM  -> mean/max = %
 print("mean wave  :", " ".join("%s %.2fM" % (n, wcs[:, i].mean() / 1e6) for i, n in enumerate(names)))
 st = altro.stats(mp.solver)
 print("kernel ms %.2f" % st.tsolve_ms)
+nb, nr, ntr = altro.work_counters(mp.solver)
+ngc = altro.confirm_counter(mp.solver)
+nbw = nb.reshape(-1, 4).max(1).astype(float)      # backward passes a wave ran = those of its busiest row (roughly)
+print("per wave: backward passes (max row) mean %.1f -> %.0fk cycles per pass, %.0f per knot; costate sweeps mean %.1f -> %.0fk cycles each" % (
+    nbw.mean(), wcs[:, 1].mean() / nbw.mean() / 1e3, wcs[:, 1].mean() / nbw.mean() / (pb.N - 1),
+    ngc.reshape(-1, 4).max(1).mean(), wcs[:, 4].mean() / max(1.0, ngc.reshape(-1, 4).max(1).mean()) / 1e3))
 # the slowest waves: which phase carries their extra time, and how many turns of the wave loop they took
 order = np.argsort(-wcs[:, 0])[:5]
 nit4 = ni.reshape(-1, 4)
