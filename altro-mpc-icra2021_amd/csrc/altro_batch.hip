@@ -42,7 +42,7 @@ struct altro_handle {
   double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lb = nullptr, *mu = nullptr,
-         *KD = nullptr;
+         *KD = nullptr, *Qz = nullptr;
   double *noise = nullptr, *noise_w = nullptr;
   int* noise_grp = nullptr;
   int noise_mode = 0;
@@ -327,6 +327,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
   p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu;
+  p.Qz = h->Qz;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta;
   p.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
@@ -532,6 +533,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemcpyAsync(h->bslot, h->bslot_h, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
     CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
     CCHK(hipMalloc(&h->KD, N * Bp * m * LW * sizeof(double)));  // N-1 gain blocks + a trash slot
+    CCHK(hipMalloc(&h->Qz, (N + 1) * row * sizeof(double)));
+    CCHK(hipMemsetAsync(h->Qz, 0, (N + 1) * row * sizeof(double), h->stream));
     CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
@@ -598,7 +601,7 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
-                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero};
+                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
   h->stage_bytes = 0;

@@ -49,7 +49,7 @@
 #define ALTRO_PD_CLOSED 4  // knots of prefetch in the closed-loop rollout (2..8 measured with the butterfly gain sums: 4 best)
 #endif
 #ifndef ALTRO_PD_ADJOINT
-#define ALTRO_PD_ADJOINT 4  // knots of prefetch in the costate sweep (12 measured: slower)
+#define ALTRO_PD_ADJOINT 8  // knots of prefetch in the costate sweep (one load per knot)
 #endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
@@ -117,6 +117,8 @@ struct SolveParams {
                          // linear rows may use the quad's spare lanes)
   double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
   int ncrows;            // 0: no generic constraints
+  double* Qz;            // [N+1][Bp][16] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced
+                         // (l_x on the state lanes, l_u on the control lanes; knot N = trash): input of the costate sweep
   double* KD;            // [N][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX; block N-1 = trash
   int* iters;
   int* iters_outer;
@@ -341,6 +343,7 @@ struct RowState {
   int phase, status, iters, iters_outer, outer, it, dj_zero, cur, kref, step, shift, last;
   int nbw, nro, nsolve, nit, nok, ntr;
   int bw_plain;   // the gains in KD come from a backward pass of THIS inner solve that ran with rho == 0
+  int qvalid;     // Qz (and the hash in qhash) describe the CURRENT trajectory: its last step was an accepted alpha = 1 rollout
   int gconf;      // the last iteration of the last solve was confirmed by the costate sweep (its d is exactly 0)
   int ngc;        // iterations confirmed by the costate sweep (work counter)
 };
@@ -354,6 +357,7 @@ struct Solver {
   RowState* rs;  // this lane's row state (LDS)
   double* sm;    // this row's 16 x 17 transpose tile (LDS)
   unsigned* ah;  // this lane's active-set hash of the last backward pass (LDS)
+  unsigned* qhs; // this lane's active-set hash of the trajectory in Qz (LDS)
   int lane, j, inst;
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
@@ -370,6 +374,7 @@ struct Solver {
   __device__ Solver(const SolveParams& p, RowState* rows, double* tiles, unsigned* hashes) : P(p) {
     lane = threadIdx.x & 63;
     ah = hashes + (threadIdx.x & 63);
+    qhs = hashes + 64 + (threadIdx.x & 63);
     j = lane & 15;
     inst = blockIdx.x * IPW + (lane >> 4);
     rs = rows + (lane >> 4);
@@ -451,6 +456,13 @@ struct Solver {
   static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
   static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+  // Active-set hash of one lane: a position-weighted sum of the 2-bit codes, so that the backward pass (knots in
+  // descending order) and the rollout (ascending) arrive at the same number for the same active set.
+  static __device__ __forceinline__ unsigned hash_add(unsigned h, unsigned code, int k) {
+    const unsigned mk = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;   // 24 bits: v_mad_u32_u24 runs at full rate
+    return __umul24(code, mk) + h;
+  }
+
   // max over the NU control lanes of this row
   __device__ __forceinline__ double umax(double v) const {
     double m = bcast<NX>(v);
@@ -462,18 +474,34 @@ struct Solver {
   // Branch-free: box_on only selects.  (oracle total_cost / con_cost; TO.jl cost! -- SURVEY A.2)
   static __device__ __forceinline__ double lane_cost(const LaneConst& c, double mu, double z, double zr, double w,
                                                      double lhi, double llo, bool box_on, double& viol) {
+    double qz;
+    unsigned code;
+    return lane_cost_grad<false>(c, mu, z, zr, w, lhi, llo, box_on, viol, qz, code);
+  }
+  // GRAD: also the gradient of the lane's AL cost term (what box_expand computes) and the 2-bit active-set code
+  template <bool GRAD>
+  static __device__ __forceinline__ double lane_cost_grad(const LaneConst& c, double mu, double z, double zr, double w,
+                                                          double lhi, double llo, bool box_on, double& viol, double& qz,
+                                                          unsigned& code) {
     const double e = z - zr;
     double Jl = 0.5 * w * e * e;
     const double chi = z - c.zmax, clo = c.zmin - z;
     const bool ahi = (chi >= 0.0) | (lhi > 0.0);
     const bool alo = (clo >= 0.0) | (llo > 0.0);
-    const double Jhi = lhi * chi + (ahi ? 0.5 * mu * chi * chi : 0.0);
-    const double Jlo = llo * clo + (alo ? 0.5 * mu * clo * clo : 0.0);
+    const double phi = ahi ? mu * chi : 0.0, plo = alo ? mu * clo : 0.0;
+    const double Jhi = lhi * chi + 0.5 * phi * chi;
+    const double Jlo = llo * clo + 0.5 * plo * clo;
     const bool bh = box_on & c.has_hi, bl = box_on & c.has_lo;
     Jl += bh ? Jhi : 0.0;
     Jl += bl ? Jlo : 0.0;
     viol = fmax(viol, bh ? chi : 0.0);
     viol = fmax(viol, bl ? clo : 0.0);
+    if constexpr (GRAD) {
+      qz = w * e;
+      qz += bh ? (lhi + phi) : 0.0;
+      qz -= bl ? (llo + plo) : 0.0;
+      code = ((bh & ahi) ? 1u : 0u) | ((bl & alo) ? 2u : 0u);
+    }
     return Jl;
   }
 
@@ -482,6 +510,7 @@ struct Solver {
     bool limit;
     bool unchanged;  // the trial reproduced plane `cur` bit for bit (closed-loop rollouts only)
     bool tiny;       // every element moved by at most 1e-7 (1 + |z|)            (closed-loop rollouts only)
+    unsigned qh;     // per lane: hash of the active set at the trajectory produced (closed-loop rollouts only)
   };
 
   struct KnotIn {
@@ -498,8 +527,9 @@ struct Solver {
   //          inner loop) send their stores to the trash slot.
   //   !OPEN: closed-loop rollout with gains KD and step alpha = 1 from plane cur into plane
   //          cur^1 (dead storage for every row that is not iterating, so stores need no mask).
+  //          storeq: rows whose gradient plane Qz this rollout refreshes (the rows that are searching).
   template <bool OPEN>
-  __device__ RollOut rollout(bool take, bool shift) {
+  __device__ RollOut rollout(bool take, bool shift, bool storeq = false) {
     __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);  // latency-bound phase: see ALTRO_PRIO_SERIAL
     const LaneConst lc = consts();
     const double mu = rs->mu;
@@ -520,6 +550,7 @@ struct Solver {
     double xb = ldg(P.x0, rowoff);
     double Jacc = 0.0, viol = 0.0;
     bool limit = false, changed = false, big = false;
+    unsigned qh = 0u;
     const int k1 = P.box_k1;
     const bool shl = OPEN && shift;           // per row
     const bool shu = shl && !is_x;            // controls are read one knot ahead
@@ -622,7 +653,15 @@ struct Solver {
         big = big | ((is_x | is_u) & !(fabs(zb - in.z) <= 1e-7 * (1.0 + fabs(in.z))));
         stg(P.Z, zd + at(k), zb);
       }
-      Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
+      if constexpr (!OPEN && !CONES) {
+        double qz;
+        unsigned code;
+        Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol, qz, code);
+        qh = hash_add(qh, code, k);
+        stg(P.Qz, at(storeq ? k : N), qz);
+      } else {
+        Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
+      }
       if constexpr (CONES) {
         const bool act = con_act(ck.cm, k);
         const double v = con_value(zb, ck.arow, ck.brow);
@@ -681,7 +720,15 @@ struct Solver {
       const double zb = is_x ? xb : 0.0;
       if constexpr (OPEN) stg(P.Z, at(take ? cur * N + kt : 2 * N), zb);
       else stg(P.Z, zd + at(kt), zb);
-      Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
+      if constexpr (!OPEN && !CONES) {
+        double qz;
+        unsigned code;
+        Jacc += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
+        qh = hash_add(qh, code, kt);
+        stg(P.Qz, at(storeq ? kt : N), is_x ? qz : 0.0);
+      } else {
+        Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
+      }
       if constexpr (CONES) {
         const bool act = con_act(t_ck.cm, kt);
         const double v = con_value(zb, t_ck.arow, t_ck.brow);
@@ -701,6 +748,7 @@ struct Solver {
     r.limit = row_any(limit, lane);
     r.unchanged = !row_any(changed, lane);
     r.tiny = !row_any(big, lane);
+    r.qh = qh;
     __builtin_amdgcn_s_setprio(0);
     return r;
   }
@@ -931,7 +979,9 @@ struct Solver {
       const double zr = ldg(P.Zref, at(kref + k));
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       double qz = lc.wf * (z - zr), hz = lc.wf;
-      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, hash);
+      unsigned codeT;
+      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
+      hash = hash_add(0u, codeT, k);
       if constexpr (CONES) {
         double hT[NZ];
         sfor<0, NZ>([&](auto c) {
@@ -980,7 +1030,7 @@ struct Solver {
       double qz = lc.wd * (z - zr), hz = lc.wd;
       unsigned code;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      hash = hash * 4u + code + (hash >> 27);
+      hash = hash_add(hash, code, k);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
       double w[NX + 1];
       sfor<0, NX + 1>([&](auto c) { w[decltype(c)::value] = 0.0; });
@@ -1119,75 +1169,40 @@ struct Solver {
   }
 
   // Costate sweep (default mode, box-only problems): lambda_N = l_x(N), lambda_k = l_x(k) + A' lambda_{k+1},
-  // g_k = l_u(k) + B' lambda_{k+1} on the current plane -- the first-order part of the backward pass, one
-  // 12-FMA product per knot instead of 396.  By induction over the knots, every feedforward term of the
-  // backward pass vanishes iff every g_k does, and |d_k| <= |g_k|_2 / lambda_min(Quu) <= 2 |g_k|_inf / (dt R):
-  // gtiny (out) says |g_k,a| <= 0.25e-9 dt R_a (1 + |u_k,a|) everywhere, i.e. |d| <= 0.5e-9 (1 + |u|).
-  // same (out): the active set of the box rows is, knot by knot, the one the last backward pass of this inner
-  // solve saw -- then the gains in KD ARE the gains the reference's confirmation pass would compute (the problem
-  // is quadratic inside an active set, so K does not depend on the iterate).
-  __device__ void adjoint(bool& gtiny, bool& same) {
+  // g_k = l_u(k) + B' lambda_{k+1} -- the first-order part of the backward pass, one 12-FMA product per knot
+  // instead of 396.  l_x, l_u at the current trajectory were left in the plane Qz by the alpha = 1 rollout that
+  // produced it (one load per knot here).  By induction over the knots every feedforward term of the backward
+  // pass vanishes iff every g_k does, and |d_k| <= |g_k|_2 / lambda_min(Quu) <= 2 |g_k|_inf / (dt R):
+  // gtiny (out) says |g_k,a| <= 0.25e-9 dt R_a at every knot, i.e. |d| <= 0.5e-9.
+  __device__ void adjoint(bool& gtiny) {
     __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
-    const LaneConst lc = consts();
-    const double mu = rs->mu;
-    const int kref = rs->kref;
-    const unsigned zs = plane(rs->cur);
     double g[NX];
     sfor<0, NX>([&](auto c) {
       constexpr int C = decltype(c)::value;
       g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
     });
+    const double thr = 0.25e-9 * P.wd[j];
     const int N = P.N;
-    unsigned hash = 0u;
     bool gbig = false;
-    double sv;
-    {
-      const int k = N - 1;
-      const double z = ldg(P.Z, zs + at(k)), zr = ldg(P.Zref, at(kref + k));
-      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
-      double qz = lc.wf * (z - zr), hz = lc.wf;
-      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, hash);
-      sv = is_x ? qz : 0.0;
-    }
-    // knots requested ahead: a knot of this sweep is only ~150 cycles of dependent work (the chain through sv),
-    // so an HBM round trip spans a dozen of them; with 4 the sweep ran at 1.3 k cycles per knot, waiting
+    double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
     constexpr int PD = ALTRO_PD_ADJOINT;
-    double rz[PD], rzr[PD], rhi[PD], rlo[PD];
-    sfor<0, PD>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      const int k = imax(N - 2 - U, 0);
-      rz[U] = ldg(P.Z, zs + at(k));
-      rzr[U] = ldg(P.Zref, at(kref + k));
-      rhi[U] = ldg(P.Lb, lb_at(k, 0));
-      rlo[U] = ldg(P.Lb, lb_at(k, 1));
-    });
-    auto stage = [&](int k, double z, double zr, double lhi, double llo, bool valid) {
-      double qz = lc.wd * (z - zr), hz = lc.wd;
-      unsigned code;
-      box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      const unsigned h2 = hash * 4u + code + (hash >> 27);
-      hash = valid ? h2 : hash;
-      double acc4[4] = {qz, 0.0, 0.0, 0.0};
-      Blk<NX, NU>::GTS(acc4, sv, g);
-      const double gz = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);  // x lanes: lambda_k, u lanes: g_k
-      gbig = gbig | (valid & is_u & !(fabs(gz) <= 0.25e-9 * lc.wd * (1.0 + fabs(z))));
-      sv = valid ? (is_x ? gz : 0.0) : sv;
-    };
+    double rq[PD];
+    sfor<0, PD>([&](auto u) { rq[decltype(u)::value] = ldg(P.Qz, at(imax(N - 2 - decltype(u)::value, 0))); });
     const int ngroups = (N - 1 + PD - 1) / PD;
     int k = N - 2;
     for (int gq = 0; gq < ngroups; ++gq, k -= PD) {  // body: one basic block
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        stage(imax(k - U, 0), rz[U], rzr[U], rhi[U], rlo[U], k - U >= 0);
-        const int kn = imax(k - U - PD, 0);
-        rz[U] = ldg(P.Z, zs + at(kn));
-        rzr[U] = ldg(P.Zref, at(kref + kn));
-        rhi[U] = ldg(P.Lb, lb_at(kn, 0));
-        rlo[U] = ldg(P.Lb, lb_at(kn, 1));
+        const bool valid = k - U >= 0;
+        double acc4[4] = {rq[U], 0.0, 0.0, 0.0};
+        Blk<NX, NU>::GTS(acc4, sv, g);
+        const double gz = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);  // x lanes: lambda_k, u lanes: g_k
+        gbig = gbig | (valid & is_u & !(fabs(gz) <= thr));
+        sv = valid ? (is_x ? gz : 0.0) : sv;
+        rq[U] = ldg(P.Qz, at(imax(k - U - PD, 0)));
       });
     }
     gtiny = !row_any(gbig, lane);
-    same = !row_any(hash != *ah, lane);
     __builtin_amdgcn_s_setprio(0);
   }
 
@@ -1279,6 +1294,7 @@ struct Solver {
       s.step = 0;
       s.nbw = s.nro = s.nsolve = s.nit = s.nok = s.ntr = 0;
       s.bw_plain = 0;
+      s.qvalid = 0;
       s.gconf = P.dzero[inst];
       s.ngc = 0;
       *rs = s;
@@ -1343,6 +1359,7 @@ struct Solver {
             rs->dj_zero = 0;
             rs->it = 0;
             rs->bw_plain = 0;
+            rs->qvalid = 0;
             rs->shift = 0;
             rs->nro += 1;
             rs->J_prev = r0.J;
@@ -1376,14 +1393,17 @@ struct Solver {
           // in such an iteration).  Any other outcome falls through to the full iteration.
           bool gconf = false;
           if constexpr (!CONES) {
-            const bool tryg = !o.strict && inner && (rs->it >= 1) && (rs->bw_plain != 0) && (rs->rho == 0.0) &&
-                              (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
+            // (same active set as the last backward pass: then its gains ARE the ones the reference's confirmation pass
+            //  would compute -- the problem is quadratic inside an active set, K does not depend on the iterate)
+            const bool same = !row_any(*qhs != *ah, lane);
+            const bool tryg = !o.strict && inner && (rs->it >= 1) && (rs->bw_plain != 0) && (rs->qvalid != 0) && same &&
+                              (rs->rho == 0.0) && (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
             if (wave_any(tryg)) {
-              bool gt, same;
+              bool gt;
               ALTRO_STAMP(long long ts = stamp();)
-              adjoint(gt, same);
+              adjoint(gt);
               ALTRO_STAMP(t_td += stamp() - ts;)
-              gconf = tryg && gt && same;
+              gconf = tryg && gt;
             }
           }
           bool bwrow = inner && !gconf;  // rows that run the backward pass of this iteration
@@ -1475,11 +1495,13 @@ struct Solver {
           };
           if (wave_any(searching)) {
             ALTRO_STAMP(long long ts = stamp();)
-            const RollOut rr = rollout<false>(true, false);
+            const RollOut rr = rollout<false>(true, false, searching);
             ALTRO_STAMP(t_rc += stamp() - ts;)
             if (searching) {
               rs->nro += 1;
               trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged, rr.tiny);
+              *qhs = rr.qh;
+              rs->qvalid = (accepted && alpha == 1.0) ? 1 : 0;  // a smaller step (or none) leaves Qz describing a rejected trial
             }
           }
           while (true) {
@@ -1643,7 +1665,7 @@ template <int NX, int NU, bool CONES>
 __global__ void __launch_bounds__(64, CONES ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
-  __shared__ unsigned hashes[64];
+  __shared__ unsigned hashes[128];
   const long long t0 = __builtin_amdgcn_s_memtime();
   Solver<NX, NU, CONES> s(p, rows, tiles, hashes);
   s.run(p.nsteps > 0, p.first_step, p.nsteps);

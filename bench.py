@@ -148,15 +148,12 @@ def cpu_baseline(budget_s=12.0):
 def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None):
     """Run W warm-up + K timed MPC steps (one fused launch) of a secondary BASELINE config on one GPU and build
     its JSON line: same metric, roofline from HIP events on the library's stream and the measured pass counts."""
-    import torch
     for i in range(W):
         mp.step(i)
-    altro.timing_reset(mp.solver)
-    torch.cuda.synchronize()
+    altro.timing_reset(mp.solver)          # synchronises the library's stream (no torch here: plumbing only)
     t0 = time.perf_counter()
     mp.run_async(K, first=W)
     mp.synchronize()
-    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = altro.timing_get(mp.solver)
     nb, nr, ntr = altro.work_counters(mp.solver)
