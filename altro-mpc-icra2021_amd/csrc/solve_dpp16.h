@@ -64,6 +64,16 @@
 // of the other wave -- hundreds of independent FMAs per knot -- fills every other slot.
 #define ALTRO_PRIO_SERIAL 1  // measured 0..3 on the headline: 1 is +1 %, 2 and 3 about the same, 0 = off
 #endif
+#ifndef ALTRO_PRIO_HARD
+// Issue priority of a wave while one of its rows is in a solve that did not end with its second iteration (a
+// "hard" solve: 3 % of them, 5-20 iterations).  Those rows are the launch's critical path -- the slowest wave
+// takes twice the mean wave's time at 20 steps per launch -- and while such a wave still shares its SIMD it
+// advances at 0.73 of the speed it reaches alone.  0 = off.
+#define ALTRO_PRIO_HARD 2
+#endif
+#ifndef ALTRO_PRIO_LAG
+#define ALTRO_PRIO_LAG 0  // measured 4 and 8 on the headline: within run-to-run noise of 0 (off)
+#endif
 #ifndef ALTRO_WAVES_PER_SIMD
 #define ALTRO_WAVES_PER_SIMD 2  // register budget: 512 / this
 #endif
@@ -356,6 +366,8 @@ struct Solver {
   const SolveParams& P;
   RowState* rs;  // this lane's row state (LDS)
   double* sm;    // this row's 16 x 17 transpose tile (LDS)
+  bool hard_wave = false;  // wave-uniform: a row of this wave is in a hard solve (see ALTRO_PRIO_HARD)
+  int turns = 0;           // turns of the wave loop so far
   unsigned* ah;  // this lane's active-set hash of the last backward pass (LDS)
   unsigned* qhs; // this lane's active-set hash of the trajectory in Qz (LDS)
   int lane, j, inst;
@@ -456,6 +468,15 @@ struct Solver {
   static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
   static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+  __device__ __forceinline__ void prio_serial() const {
+    if (ALTRO_PRIO_HARD > 0 && hard_wave) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HARD < 3 ? ALTRO_PRIO_HARD + 1 : 3);
+    else __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
+  }
+  __device__ __forceinline__ void prio_base() const {
+    if (ALTRO_PRIO_HARD > 0 && hard_wave) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HARD);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+
   // Active-set hash of one lane: a position-weighted sum of the 2-bit codes, so that the backward pass (knots in
   // descending order) and the rollout (ascending) arrive at the same number for the same active set.
   static __device__ __forceinline__ unsigned hash_add(unsigned h, unsigned code, int k) {
@@ -530,7 +551,7 @@ struct Solver {
   //          storeq: rows whose gradient plane Qz this rollout refreshes (the rows that are searching).
   template <bool OPEN>
   __device__ RollOut rollout(bool take, bool shift, bool storeq = false) {
-    __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);  // latency-bound phase: see ALTRO_PRIO_SERIAL
+    prio_serial();  // latency-bound phase: see ALTRO_PRIO_SERIAL
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const int cur = rs->cur, kref = rs->kref;
@@ -749,14 +770,14 @@ struct Solver {
     r.unchanged = !row_any(changed, lane);
     r.tiny = !row_any(big, lane);
     r.qh = qh;
-    __builtin_amdgcn_s_setprio(0);
+    prio_base();
     return r;
   }
 
   // gradient_todorov!: mean_k max_a |d_k,a| / (|u_k,a| + 1) on the current plane.  Evaluated
   // lazily: the reference only uses it in the convergence test, which also needs dJ < tol.
   __device__ double todorov() {
-    __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
+    prio_serial();
     const unsigned zs = plane(rs->cur);
     const int N = P.N;
     const int ra = is_u ? (j - NX) : 0;
@@ -779,7 +800,7 @@ struct Solver {
         acc += (k0 + Tt < N - 1) ? m : 0.0;
       });
     }
-    __builtin_amdgcn_s_setprio(0);
+    prio_base();
     return acc / (double)(N - 1);
   }
 
@@ -1175,7 +1196,7 @@ struct Solver {
   // pass vanishes iff every g_k does, and |d_k| <= |g_k|_2 / lambda_min(Quu) <= 2 |g_k|_inf / (dt R):
   // gtiny (out) says |g_k,a| <= 0.25e-9 dt R_a at every knot, i.e. |d| <= 0.5e-9.
   __device__ void adjoint(bool& gtiny) {
-    __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
+    prio_serial();
     double g[NX];
     sfor<0, NX>([&](auto c) {
       constexpr int C = decltype(c)::value;
@@ -1203,7 +1224,7 @@ struct Solver {
       });
     }
     gtiny = !row_any(gbig, lane);
-    __builtin_amdgcn_s_setprio(0);
+    prio_base();
   }
 
   // dual_update! for the box rows of plane `cur` (penalty_update! is the caller's mu *= phi)
@@ -1379,6 +1400,16 @@ struct Solver {
 
       // ---------------- C. one iLQR iteration for the rows inside their inner loop
       bool upd = false;  // rows that need a dual update after this turn
+      {
+        // ... and for the rest of the launch once the wave trails the two-turns-per-step pace by ALTRO_PRIO_LAG turns:
+        // its partner on the SIMD has that much slack, the launch does not
+        turns++;
+        const RowState* r0 = rs - (lane >> 4);
+        int ms = r0[0].step;
+        sfor<1, IPW>([&](auto q) { ms = imin(ms, r0[decltype(q)::value].step); });
+        hard_wave = wave_any((rs->phase == PH_ITER) && (rs->iters >= 2)) || (ALTRO_PRIO_LAG > 0 && turns - 2 * ms >= ALTRO_PRIO_LAG + 2);
+      }
+      prio_base();
       {
         bool inner = (rs->phase == PH_ITER) && (rs->it < o.iterations_inner) && (rs->status <= ALTRO_SOLVE_SUCCEEDED);
         bool inner_end = (rs->phase == PH_ITER) && !inner;  // loop exhausted / aborted before this turn
