@@ -5,7 +5,7 @@ declared in include/altro_batch.h.  This package mirrors the Altro.jl /
 TrajectoryOptimization.jl call surface the reference's benchmark scripts use (api.py) and
 restates the reference's problem generators and MPC harness (problems.py, mpc.py).
 """
-from . import _lib, benchmarks, mpc, parallel, problems  # noqa: F401
+from . import _lib, benchmarks, mpc, parallel, problems, results_io  # noqa: F401
 from ._lib import SOLVE_SUCCEEDED, STATUS_NAMES  # noqa: F401
 from .api import alpha_trace, gains, set_dynamics, set_dynamics_track  # noqa: F401
 from .api import (ALTROSolver, AltroError, BoundConstraint, ConstraintList, GoalConstraint, LinearConstraint,

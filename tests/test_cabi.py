@@ -80,3 +80,25 @@ def test_integration_doc_binds_every_export():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = [s for s in altro._lib.EXPORTS if (":" + s) not in doc]
     assert not missing, missing
+
+
+def test_result_writer_round_trip(tmp_path):
+    """results_io.write_results: the reference's result shape (`results` Dicts + `Ns`, random_linear_problem.jl:188,
+    run_random_linear.jl:125) as plain HDF5; read back through the HDF5 library, which also opens the reference's own
+    JLD2 files (they are HDF5 with a user block)."""
+    import numpy as np
+    import altro_amd_loader  # noqa: F401
+    from altro_mpc_icra2021_amd import results_io as R
+    try:
+        R._lib()
+    except RuntimeError:
+        pytest.skip("no libhdf5 on this machine")
+    res = [{"time": np.arange(5.0) + i, "iter": np.full((5, 8), 2 + i), "batch": 8} for i in range(3)]
+    p = R.write_results(str(tmp_path / "horizon_comp.h5"), [11, 31, 51], res)
+    assert R.read_dataset(p, "Ns").tolist() == [11, 31, 51]
+    t = R.read_dataset(p, "results/2/time")              # HDF5 sees [C, steps]; Julia reads it as [steps, C]
+    assert t.shape == (1, 5) and np.allclose(t[0], (np.arange(5.0) + 1) / 8)
+    assert R.read_dataset(p, "results/3/iter").tolist() == [[4] * 5]
+    res2 = [{"time": np.ones((7, 2)), "iter": np.full((7, 2), 2)}]
+    p2 = R.write_results(str(tmp_path / "two_columns.h5"), [21], res2)
+    assert R.read_dataset(p2, "results/1/time").shape == (2, 7)
