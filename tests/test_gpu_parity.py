@@ -867,6 +867,16 @@ def test_grasp_cold_solve_matches_oracle_and_reference_fixture(oracle):
     # the reference's stored solver output
     assert np.abs(X[0, :, 1] - y).max() < 1e-6 and np.abs(X[0, :, 2] - z).max() < 1e-6
     assert np.abs(U[0, :, 1:3] - F1).max() < 1e-6 and np.abs(U[0, :, 4:6] - F2).max() < 1e-6
+    # ... and the reference's OWN solve, iterate path included: with the options that solve effectively ran with
+    # (old/altro_cold_solve.jl:79-86: the AL stage at the polish tolerance 1e-5, the polish itself skipped; see
+    # tests/test_oracle_cones.py) the kernels reproduce the stored trajectory to rounding after the same 17 iterations
+    ref_opts = dict(cost_tolerance_intermediate=1e-5, constraint_tolerance=1e-5, penalty_initial=1.0, penalty_scaling=10.0)
+    sv2 = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0[:1]), altro.SolverOptions(**ref_opts))
+    altro.solve(sv2)
+    s2, X2, U2 = altro.stats(sv2), altro.states(sv2), altro.controls(sv2)
+    assert int(s2.status[0]) == 1 and int(s2.iterations[0]) == 17 and int(s2.iterations_outer[0]) == 5
+    assert np.abs(X2[0, :, 1] - y).max() < 1e-10 and np.abs(X2[0, :, 2] - z).max() < 1e-10
+    assert np.abs(U2[0, :, 1:3] - F1).max() < 1e-10 and np.abs(U2[0, :, 4:6] - F2).max() < 1e-10
 
 
 def test_grasp_mpc_loop_with_per_step_constraint_updates_matches_oracle(oracle):
