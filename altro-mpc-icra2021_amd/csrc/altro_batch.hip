@@ -420,6 +420,7 @@ int32_t altro_default_opts(altro_opts* o) {
     o->bp_reg = 0;
     o->soc_second_order = 1;
     o->strict = 0;
+    o->kickout_max_penalty = 0;
     return ALTRO_OK;
   });
 }

@@ -1635,7 +1635,7 @@ struct Solver {
             finished = true;
           } else if (status > ALTRO_SOLVE_SUCCEEDED) {
             finished = true;
-          } else if (cmax < o.constraint_tolerance || rs->mu >= o.penalty_max) {
+          } else if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && rs->mu >= o.penalty_max)) {
             finished = true;
           } else if (rs->last) {
             rs->status = ALTRO_MAX_ITERATIONS_OUTER;

@@ -1277,7 +1277,7 @@ struct Solver {
                  last ? o.gradient_tolerance : o.gradient_tolerance_intermediate, cmax);
         iters_outer++;
         if (status > ALTRO_SOLVE_SUCCEEDED) break;
-        if (cmax < o.constraint_tolerance || mu >= o.penalty_max) break;
+        if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && mu >= o.penalty_max)) break;
         if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
         dual_update();
         mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);

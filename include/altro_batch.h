@@ -117,6 +117,11 @@ typedef struct altro_opts {
    * 1: none of them, the reference's exact sequence (about half the throughput on BASELINE's headline workload).
    * The one-wave-per-instance kernel always runs the exact sequence. */
   int32_t strict;
+  /* Altro.SolverOptions.kickout_max_penalty (default false): with 0 the AL outer loop does not stop when the penalty
+   * has reached penalty_max -- it goes on with dual updates at the cap until the constraints are satisfied or
+   * iterations_outer runs out (MAX_ITERATIONS_OUTER); 1 ends the solve there (status UNSOLVED if the violation is
+   * still above the tolerance). */
+  int32_t kickout_max_penalty;
 } altro_opts;
 
 #define ALTRO_TRACE_LEN 16 /* per-instance trace depth kept on device */

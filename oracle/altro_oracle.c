@@ -81,6 +81,7 @@ void orc_default_opts(orc_opts* o) {
   o->reset_penalties = 1;
   o->bp_reg = 0;
   o->soc_second_order = 1;
+  o->kickout_max_penalty = 0;
 }
 
 /* ---------------------------------------------------------------- lifecycle */
@@ -848,7 +849,7 @@ void orc_solve(orc_solver* s) {
     st->iterations_outer = jo + 1;
     if (st->status > ORC_SOLVE_SUCCEEDED) break;
     /* evaluate_convergence(::AugmentedLagrangianSolver) */
-    if (cmax < o->constraint_tolerance || penalty_max_now(s) >= o->penalty_max) break;
+    if (cmax < o->constraint_tolerance || (o->kickout_max_penalty && penalty_max_now(s) >= o->penalty_max)) break;
     if (j == o->iterations_outer - 1) { st->status = ORC_MAX_ITERATIONS_OUTER; break; }
     dual_penalty_update(s);
   }

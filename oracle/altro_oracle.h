@@ -79,6 +79,8 @@ typedef struct {
   int reset_penalties;                 /* 1 */
   int bp_reg;                          /* 0 */
   int soc_second_order;                /* 1: add the projection-curvature term to the SOC Hessian */
+  int kickout_max_penalty;             /* 0 (Altro.jl's default): the AL loop does NOT stop when the penalty reaches
+                                          penalty_max, it goes on updating duals at the cap; 1: it stops there */
 } orc_opts;
 
 #define ORC_TRACE_MAX 256

@@ -30,7 +30,8 @@ class Opts(C.Structure):
         "bp_reg_initial", "bp_reg_increase_factor", "bp_reg_max", "bp_reg_min", "bp_reg_fp")] + \
         [(k, C.c_int) for k in (
             "iterations", "iterations_inner", "iterations_outer", "iterations_linesearch",
-            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order")]
+            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order",
+            "kickout_max_penalty")]
 
 
 class Stats(C.Structure):
