@@ -233,6 +233,7 @@ struct Solver {
   int cur, kref;
   double mu, rho, drho;
   int dj_zero, status, iters, iters_outer;
+  bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
   long long nbw, nro, ntr;
   long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
   // per-lane constants (lane T as state element T and as control element T), loaded once
@@ -317,6 +318,72 @@ struct Solver {
     return dot_strided(Bk(k) + T, n, zb + np, m, acc);
   }
 
+  // Per-knot dynamics one knot ahead (n, m <= 16).  A wave that asked for knot k's [A_k B_k f_k] when it needed them
+  // waited for four dependent batches of strided loads per rollout knot and five per backward knot, ~2 us each from
+  // HBM with one wave per SIMD and nothing else to run.  Instead the block of the NEXT knot is requested into nine
+  // registers per lane while the current knot is processed and parked in LDS afterwards: the rollouts keep it in
+  // global-memory order in W and Hux alternately (both are scratch outside the backward pass), the backward pass
+  // writes it into G once the last product that reads G has issued.
+  struct DynRegs {
+    double a[4], b[4], f;
+  };
+  __device__ __forceinline__ bool dyn_ahead() const { return P.ltv && n <= 16 && m <= 16; }
+  __device__ __forceinline__ DynRegs dyn_request(int k) const {
+    const double *A_ = Ak(k), *B_ = Bk(k);
+    const int nn = n * n, nm = n * m;
+    DynRegs d;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = T + 64 * u;
+      d.a[u] = A_[e < nn ? e : nn - 1];
+      d.b[u] = B_[e < nm ? e : nm - 1];
+    }
+    d.f = fk(k)[T < n ? T : n - 1];
+    return d;
+  }
+  __device__ __forceinline__ void dyn_park_linear(const DynRegs& d, lds_d* st) const {
+    const int nn = n * n, nm = n * m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = T + 64 * u;
+      if (e < nn) st[e] = d.a[u];
+      if (e < nm) st[nn + e] = d.b[u];
+    }
+    if (T < n) st[nn + nm + T] = d.f;
+  }
+  __device__ __forceinline__ void dyn_park_G(const DynRegs& d) {
+    const int nn = n * n, nm = n * m;
+    Walk w = start(by_n);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = T + 64 * u;
+      if (e < nn) G[w.r * ly.ldg + w.q] = d.a[u];
+      if (e < nm) G[w.r * ly.ldg + np + w.q] = d.b[u];
+      step(by_n, w);
+    }
+  }
+  // sum_j col[j * stride] * vec[j] over an LDS column, terms in the order of dot_strided
+  static __device__ __forceinline__ double dot_lds_col(const lds_d* col, int stride, const lds_d* vec, int cnt, double acc) {
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = col[(j0 + u < cnt ? j0 + u : cnt - 1) * stride];
+        b[u] = vec[j0 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += a[u] * b[u];
+    }
+    return acc;
+  }
+  // next_state(k) from a block parked by dyn_park_linear
+  __device__ __forceinline__ double next_state_parked(const lds_d* st) const {
+    const int nn = n * n, nm = n * m;
+    double acc = st[nn + nm + T];
+    acc = dot_lds_col(st + T, n, (const lds_d*)zb, n, acc);
+    return dot_lds_col(st + nn + T, n, (const lds_d*)zb + np, m, acc);
+  }
+
   // AL cost of one box-bounded element
   static __device__ __forceinline__ double lane_cost(double w, double z, double zr, double zmx, double zmn, double lhi,
                                                      double llo, double mu, bool box_on, double& viol) {
@@ -361,6 +428,8 @@ struct Solver {
   struct RollOut {
     double J, cmax;
     bool limit;
+    bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
+    bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
   };
 
   // ---- second-order cone rows (oracle soc_project / con_cost / cost_expansion) -------------
@@ -613,7 +682,7 @@ struct Solver {
     const double* grow = G + Tn * ly.ldg;
     const double fT = fk(0)[Tn];
     double J = 0.0, viol = 0.0;
-    bool lim = false;
+    bool lim = false, chg = false, big = false;
     double xb = isx ? x0i[Tn] : 0.0;
     struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
     auto ld = [&](int k) {
@@ -650,6 +719,10 @@ struct Solver {
       }
       const double uv = acc;
       *uslot = uv;
+      if (CLOSED) {
+        chg = chg | (isx & (xb != d.xs)) | (isu & (uv != d.us));
+        big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs)))) | (isu & !(fabs(uv - d.us) <= 1e-7 * (1.0 + fabs(d.us))));
+      }
       wsync();
       J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
       J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
@@ -664,11 +737,17 @@ struct Solver {
     wsync();
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
     lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));
+    if (CLOSED) {
+      chg = chg | (isx & (xb != d.xs));
+      big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
+    }
     __syncthreads();
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
     r.limit = wave_any(lim);
+    r.unchanged = CLOSED && !wave_any(chg);
+    r.tiny = CLOSED && !wave_any(big);
     return r;
   }
 
@@ -686,12 +765,20 @@ struct Solver {
     double* Xd = open ? Xp(cur) : Xp(cur ^ 1);
     double* Ud = open ? Up(cur) : Up(cur ^ 1);
     double J = 0.0, viol = 0.0;
-    bool lim = false;
+    bool lim = false, chg = false, big = false;
     double xb = T < n ? x0i[T] : 0.0;
     KnotLd d = load_knot(0, false, open ? 1 : 0, Xs, Us);
+    const bool ahead = dyn_ahead();
+    lds_d* const park[2] = {(lds_d*)W, (lds_d*)Hux};
+    DynRegs dq = {};
+    if (ahead) {
+      dq = dyn_request(0);
+      dyn_park_linear(dq, park[0]);  // visible after the first barrier of the loop
+    }
     for (int k = 0; k < N - 1; ++k) {
       const bool last = k == N - 2;
       const KnotLd dn = load_knot(k + 1, last, open ? 1 : 0, Xs, Us);   // knot N-1 is the terminal knot
+      if (ahead) dq = dyn_request(last ? k : k + 1);
       if (T < n) {
         zb[T] = xb;
         if (!open) dxv[T] = xb - d.xs;
@@ -714,8 +801,13 @@ struct Solver {
       wsync();
       eval_knot(k, false, xb, uv, d, J, viol);
       lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value)) || (T < m && !(fabs(uv) <= P.o.max_control_value));
+      if (!open) {
+        chg = chg | (T < n && xb != d.xs) | (T < m && uv != d.us);
+        big = big | (T < n && !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs)))) | (T < m && !(fabs(uv - d.us) <= 1e-7 * (1.0 + fabs(d.us))));
+      }
       double xn = 0.0;
-      if (T < n) xn = next_state(k);
+      if (T < n) xn = ahead ? next_state_parked(park[k & 1]) : next_state(k);
+      if (ahead) dyn_park_linear(dq, park[(k & 1) ^ 1]);
       wsync();
       xb = xn;
       d = dn;
@@ -727,11 +819,17 @@ struct Solver {
     wsync();
     eval_knot(N - 1, true, xb, 0.0, d, J, viol);
     lim = lim || (T < n && !(fabs(xb) <= P.o.max_state_value));
+    if (!open) {
+      chg = chg | (T < n && xb != d.xs);
+      big = big | (T < n && !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
+    }
     __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
     r.limit = wave_any(lim);
+    r.unchanged = !open && !wave_any(chg);
+    r.tiny = !open && !wave_any(big);
     return r;
   }
 
@@ -944,11 +1042,17 @@ struct Solver {
     dV2 = 0.0;
     wsync();
     KnotLd kd = load_knot(N - 2, false, 2, Xp(cur), Up(cur));
+    bool dbig = false;
+    const bool ahead = dyn_ahead();
+    if (ahead) load_dyn(N - 2);
     for (int k = N - 2; k >= 0; --k) {
       WSTAMP(const long long b0 = wstamp();)
       const KnotLd kdn = load_knot(k > 0 ? k - 1 : 0, false, 2, Xp(cur), Up(cur));  // operands of the next knot, one knot ahead
-      if (P.ltv) load_dyn(k);
+      DynRegs dq = {};
+      if (ahead) dq = dyn_request(k > 0 ? k - 1 : 0);
+      else if (P.ltv) load_dyn(k);
       expansion(k, false, kd);  // ends with a barrier
+      const double us_k = kd.us;
       kd = kdn;
       WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
       // Q_z = l_z + [A B]' s
@@ -960,6 +1064,7 @@ struct Solver {
       gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
       gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
       wsync();
+      if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
       WSTAMP(t_gemm += wstamp() - tg;)
       if (T < n) S[T * lds + T] += hz[T];
       if (T < m) {
@@ -1020,6 +1125,7 @@ struct Solver {
           const double d = Kl[T * ldh + np];
           p1 = d * Hux[T * ldh + np];
           p2 = d * d;
+          dbig = dbig | !(fabs(d) <= 1e-9 * (1.0 + fabs(us_k)));
         }
         double t1 = 0.0, dd = 0.0;
         for (int a = 0; a < m; ++a) {  // m terms in the oracle's order; v_readlane is far cheaper than a 6-step shuffle tree
@@ -1054,6 +1160,7 @@ struct Solver {
       wsync();
       WSTAMP(t_d += wstamp() - b3;)
     }
+    dtiny = !wave_any(dbig);
     return false;
   }
 
@@ -1117,7 +1224,17 @@ struct Solver {
       J = __builtin_inf();
       int ls = 0;
       bool accepted = true;
-      while ((z <= o.line_search_lower_bound || z > o.line_search_upper_bound) && J >= J_prev) {
+      // Default-mode shortcuts, the ones of solve_dpp16.h (altro_opts.strict = 1 takes none of them).  Confirmation
+      // iteration: every feedforward term of the backward pass is at rounding level, so the rollout, its line search
+      // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
+      // the outcome -- the iteration is booked as converged on the trajectory it holds.
+      const bool confirm = !o.strict && dtiny && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
+      if (confirm) {
+        J = J_prev;
+        cm = cmax;
+        accepted = false;
+      }
+      while (!confirm && (z <= o.line_search_lower_bound || z > o.line_search_upper_bound) && J >= J_prev) {
         if (ls > o.iterations_linesearch) {
           J = J_prev;
           cm = cmax;
@@ -1138,8 +1255,13 @@ struct Solver {
         z = expected > 0.0 ? (J_prev - J) / expected : -1.0;
         ls++;
         alpha *= 0.5;
+        // a trial that reproduced the trajectory bit for bit: every smaller step does too, the search would spin to
+        // its limit and fail (exact, also in strict mode).  A trial that moved nothing by more than 1e-7 (1 + |z|)
+        // while the model promises less than cost_tol / 1000: the iteration ends the same way whatever follows.
+        if (r.unchanged || (!o.strict && r.tiny && !(expected > 1e-3 * cost_tol))) ls = o.iterations_linesearch + 1;
       }
       if (accepted) alpha *= 2.0;
+      if (confirm) alpha = 1.0;
       if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
       if (accepted) cur ^= 1;  // copy_trajectories!
       cmax = cm;
@@ -1152,7 +1274,7 @@ struct Solver {
       }
       iters++;
       dj_zero = (dJ == 0.0) ? dj_zero + 1 : 0;
-      if (dJ < cost_tol && todorov() < grad_tol) break;
+      if (dJ < cost_tol && (confirm || todorov() < grad_tol)) break;
       if (iters >= o.iterations) { status = ALTRO_MAX_ITERATIONS; break; }
       if (dj_zero > o.dJ_counter_limit) { status = ALTRO_NO_PROGRESS; break; }
     }
