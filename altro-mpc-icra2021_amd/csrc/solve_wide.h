@@ -189,9 +189,13 @@ __device__ __forceinline__ long long wstamp() {
 #endif
 
 // MC: control-size class the instantiation is compiled for.  4/8/12/16: m <= MC, Quu is factored in
-// registers (factor_solve_regs<MC>); 0: m > 16, the LDS factorisation.  One kernel that switched
+// registers (factor_solve_lane<MC>); 0: m > 16, the LDS factorisation.  One kernel that switched
 // between all of them at run time needed the registers of the largest (512, one wave per SIMD).
-template <int MC>
+// SM: n <= 16 and m <= 16, every matrix of the knot is a single 16 x 16 tile.  The padded sizes and the leading
+// dimensions of the LDS carve-up are then compile-time constants: the tile loops of the products collapse into
+// straight-line MFMA chains with immediate LDS offsets, and a few dozen wave-uniform values leave the SGPR file
+// (the generic kernel spills SGPRs into VGPR lanes -- ~500 v_readlane per knot).
+template <int MC, bool SM>
 struct Solver {
   const Params& P;
   const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
@@ -240,8 +244,8 @@ struct Solver {
   double cwx = 0.0, cwfx = 0.0, cxmax = __builtin_inf(), cxmin = -__builtin_inf(), cwu = 0.0, cumax = __builtin_inf(), cumin = -__builtin_inf();
 
   __device__ __forceinline__ Solver(const Params& p, double* lds)
-      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(p.np), mp(p.mp), nz(p.n + p.m),
-        nzp(p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(p.n, p.m, p.Pn)) {
+      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
+        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn)) {
     G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
     Ac = lds + ly.Ac; DA = lds + ly.DA;
     double* v = lds + ly.vec;
@@ -964,59 +968,73 @@ struct Solver {
     return __hiloint2double((int)hi, (int)lo);
   }
 
-  // Quu_reg = L D L' and K = -Quu_reg^-1 [Qux | Qu] with the matrices in REGISTERS (m <= MP <= 16):
-  // lane b < m holds column b of Quu_reg, lane c holds column c of [Qux | Qu]; the scalars of L are
-  // handed round with v_readlane.  The LDS version below walks dependent read-modify-write chains
-  // (~128 cycles per element: 40 k cycles per knot at m = 12); this one is a few hundred VALU
-  // instructions.  Returns true if a pivot is not positive.
+  // Quu_reg = L D L' and K = -Quu_reg^-1 [Qux | Qu], every lane for itself (m <= MP <= 16): the lower triangle of
+  // Quu_reg is read from LDS by all lanes (one broadcast read per element), factored redundantly in registers
+  // (right-looking, in place) and lane c solves for column c of [Qux | Qu].  No cross-lane traffic and no branches:
+  // rows >= m are the identity (Huu's pads are exact zeros, the diagonal is set to 1), so the unrolled MP x MP code
+  // is exact for any m <= MP.  History: the LDS version walked dependent read-modify-write chains (40 k cycles per
+  // knot at m = 12); a version that kept column b on lane b and handed the scalars round with v_readlane was
+  // ~2800 instructions, 13 k cycles with one wave per SIMD; this one is ~900.  Returns true if a pivot is not positive.
+  static __device__ __forceinline__ double rcp_nr(double x) {  // 1/x to full FP64 accuracy (x > 0, normal range)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+  }
   template <int MP>
-  __device__ __forceinline__ bool factor_solve_regs() {
+  __device__ __forceinline__ bool factor_solve_lane() {
     const int ldh = ly.ldh, ldu = ly.ldu;
-    double cL[MP], invd[MP];
+    const lds_d* Hl = (const lds_d*)Huu;
+    double a[MP][MP], inv[MP];
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
-      cL[i] = (T < m && i < m) ? Huu[i * ldu + T] : 0.0;
-      invd[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < i; ++j) a[i][j] = Hl[i * ldu + j];
+      const double dii = Hl[i * ldu + i];
+      a[i][i] = i < m ? dii : 1.0;
     }
     bool fail = false;
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
-      if (j < m) {
-        const double dj = lane_bcast(cL[j], j);
-        fail = fail || !(dj > 0.0);
-        invd[j] = 1.0 / dj;
-        const double f = cL[j] * invd[j];  // lane b > j: A[j][b] / d_j = L[b][j]
+      const double dj = a[j][j];
+      fail = fail | !(dj > 0.0);
+      inv[j] = rcp_nr(dj);
+      double f[MP];
 #pragma unroll
-        for (int i = j + 1; i < MP; ++i) {
-          const double aij = lane_bcast(cL[i], j);  // A[i][j] = L[i][j] d_j
-          cL[i] = (T > j) ? cL[i] - aij * f : ((T == j) ? cL[i] * invd[j] : cL[i]);
-        }
-      }
+      for (int c = j + 1; c < MP; ++c) f[c] = a[c][j] * inv[j];  // L[c][j]
+#pragma unroll
+      for (int i = j + 1; i < MP; ++i)
+#pragma unroll
+        for (int c = j + 1; c <= i; ++c) a[i][c] -= a[i][j] * f[c];
+#pragma unroll
+      for (int c = j + 1; c < MP; ++c) a[c][j] = f[c];
     }
     if (fail) return true;  // wave-uniform: every lane saw the same pivots
-    // lane j now holds d_j in cL[j] and L[i][j] in cL[i], i > j
     for (int c0 = 0; c0 <= np; c0 += 64) {
       const int c = c0 + T;
       const bool mine = (c < n) || (c == np);
+      const lds_d* hc = (const lds_d*)Hux + (mine ? c : 0);
       double q[MP];
 #pragma unroll
-      for (int a = 0; a < MP; ++a) q[a] = (mine && a < m) ? Hux[a * ldh + c] : 0.0;
+      for (int r = 0; r < MP; ++r) {
+        const double v = hc[r * ldh];
+        q[r] = r < m ? v : 0.0;
+      }
 #pragma unroll
       for (int k = 0; k < MP; ++k)          // forward: L y = b
 #pragma unroll
-        for (int i = k + 1; i < MP; ++i)
-          if (i < m) q[i] -= lane_bcast(cL[i], k) * q[k];
+        for (int i = k + 1; i < MP; ++i) q[i] -= a[i][k] * q[k];
 #pragma unroll
-      for (int a = 0; a < MP; ++a) q[a] *= invd[a];  // 1/d_a (zero beyond m)
+      for (int r = 0; r < MP; ++r) q[r] *= inv[r];
 #pragma unroll
       for (int k = MP - 1; k >= 0; --k)     // backward: L' x = y
 #pragma unroll
-        for (int i = 0; i < k; ++i)
-          if (k < m) q[i] -= lane_bcast(cL[k], i) * q[k];
+        for (int i = 0; i < k; ++i) q[i] -= a[k][i] * q[k];
       if (mine) {
 #pragma unroll
-        for (int a = 0; a < MP; ++a)
-          if (a < m) Kl[a * ldh + c] = -q[a];
+        for (int r = 0; r < MP; ++r)
+          if (r < m) Kl[r * ldh + c] = -q[r];
       }
     }
     return false;
@@ -1084,7 +1102,7 @@ struct Solver {
       if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
       wsync();
       if constexpr (MC > 0) {
-        if (factor_solve_regs<MC>()) return true;
+        if (factor_solve_lane<MC>()) return true;
       } else {
         // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
         for (int j = 0; j < m; ++j) {
@@ -1463,30 +1481,31 @@ struct Solver {
 // waves per SIMD the register allocator is held to, per control-size class
 constexpr int wide_waves(int MC) { return (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
 
-template <int MC>
+template <int MC, bool SM>
 __global__ void __launch_bounds__(64, wide_waves(MC)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
-  Solver<MC> s(P, lds);
+  Solver<MC, SM> s(P, lds);
   s.run(mpc, first_step, nsteps);
 }
 
 // the separate shift_fill call of the fine-grained ABI
 __global__ void __launch_bounds__(64) wide_shift_kernel(Params P, int primal, int dual) {
   extern __shared__ double lds[];
-  Solver<0> s(P, lds);
+  Solver<0, false> s(P, lds);
   s.cur = P.cur[s.inst];
   s.shift(primal != 0, dual != 0);
 }
 
 typedef void (*wide_kernel_t)(Params, int, int, int);
 inline int wide_class(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : 0; }
-inline wide_kernel_t wide_kernel_for(int m) {
+inline wide_kernel_t wide_kernel_for(int n, int m) {
+  const bool sm = n <= 16 && m <= 16;
   switch (wide_class(m)) {
-    case 4: return wide_kernel<4>;
-    case 8: return wide_kernel<8>;
-    case 12: return wide_kernel<12>;
-    case 16: return wide_kernel<16>;
-    default: return wide_kernel<0>;
+    case 4: return sm ? wide_kernel<4, true> : wide_kernel<4, false>;
+    case 8: return sm ? wide_kernel<8, true> : wide_kernel<8, false>;
+    case 12: return sm ? wide_kernel<12, true> : wide_kernel<12, false>;
+    case 16: return sm ? wide_kernel<16, true> : wide_kernel<16, false>;
+    default: return wide_kernel<0, false>;
   }
 }
 
