@@ -239,7 +239,7 @@ struct Solver {
   int dj_zero, status, iters, iters_outer;
   bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
   long long nbw, nro, ntr;
-  long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+  long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_du = 0, t_sh = 0, t_run = 0, t_td = 0;
   // per-lane constants (lane T as state element T and as control element T), loaded once
   double cwx = 0.0, cwfx = 0.0, cxmax = __builtin_inf(), cxmin = -__builtin_inf(), cwu = 0.0, cumax = __builtin_inf(), cumin = -__builtin_inf();
 
@@ -1073,106 +1073,223 @@ struct Solver {
       const double us_k = kd.us;
       kd = kdn;
       WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
-      // Q_z = l_z + [A B]' s
-      for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
-      WSTAMP(const long long tg = wstamp();)
-      gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
-      wsync();
-      gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
-      gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
-      gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
-      wsync();
-      if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
-      WSTAMP(t_gemm += wstamp() - tg;)
-      if (T < n) S[T * lds + T] += hz[T];
-      if (T < m) {
-        Huu[T * ldu + T] += hz[np + T];
-        Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
-      }
-      wsync();
-      if (Pn > 0) {
-        gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
-        gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
-        gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
+      WSTAMP(long long b3 = 0;)
+      if constexpr (SM) {
+        // n, m <= 16: every operand is one 16 x 16 tile and the whole chain of products stays in registers.  The C/D
+        // layout of v_mfma_f64_16x16x4 (row = lane / 16 + 4 reg, column = lane % 16) is exactly the B fragment of
+        // k-step reg, and the fragment of G that serves as B operand of W = S G serves as A operand of G' W: twelve
+        // LDS reads feed all five products, W never touches LDS, Qxx waits in its accumulator for Qux' K.
+        for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // Q_z = l_z + [A B]' s
+        WSTAMP(const long long tg = wstamp();)
+        const int q4 = T >> 4, r16 = T & 15;
+        const lds_d* Sl = (const lds_d*)S + q4 * lds + r16;
+        const lds_d* Gl = (const lds_d*)G + q4 * ldg + r16;
+        double sA[4], gA[4], gB[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sA[r] = Sl[4 * r * lds];
+          gA[r] = Gl[4 * r * ldg];
+          gB[r] = Gl[4 * r * ldg + 16];
+        }
+        if (ahead) dyn_park_G(dq);  // LDS operations of a wave execute in order: the reads above are ahead of these writes
+        d4_t wA = {0.0, 0.0, 0.0, 0.0}, wB = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          wA = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r], gA[r], wA, 0, 0, 0);  // W = S [A B]
+          wB = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r], gB[r], wB, 0, 0, 0);
+        }
+        d4_t qxx = {0.0, 0.0, 0.0, 0.0}, qux = {0.0, 0.0, 0.0, 0.0}, quu = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qxx = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[r], wA[r], qxx, 0, 0, 0);  // A' S A
+          qux = __builtin_amdgcn_mfma_f64_16x16x4f64(gB[r], wA[r], qux, 0, 0, 0);  // B' S A
+          quu = __builtin_amdgcn_mfma_f64_16x16x4f64(gB[r], wB[r], quu, 0, 0, 0);  // B' S B
+        }
+        if (Pn > 0) {  // + A_c' diag(I_mu) A_c of the generic rows, same chains
+          const lds_d* Dl = (const lds_d*)DA + q4 * ldg + r16;
+          const lds_d* Al = (const lds_d*)Ac + q4 * ldg + r16;
+          for (int r = 0; 4 * r < Pp; ++r) {  // up to 64 rows
+            const double dx = Dl[4 * r * ldg], du = Dl[4 * r * ldg + 16], ax = Al[4 * r * ldg], au = Al[4 * r * ldg + 16];
+            qxx = __builtin_amdgcn_mfma_f64_16x16x4f64(dx, ax, qxx, 0, 0, 0);
+            qux = __builtin_amdgcn_mfma_f64_16x16x4f64(du, ax, qux, 0, 0, 0);
+            quu = __builtin_amdgcn_mfma_f64_16x16x4f64(du, au, quu, 0, 0, 0);
+          }
+        }
+        WSTAMP(t_gemm += wstamp() - tg;)
+        {
+          const double hx = hz[r16], hu = hz[np + r16] + (r16 < m ? rho : 0.0);  // diagonals: l_xx, l_uu + rho (bp_reg_type = :control)
+          lds_d* Hq = (lds_d*)Hux + q4 * ldh + r16;
+          lds_d* Uq = (lds_d*)Huu + q4 * ldu + r16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool dg = (q4 + 4 * r) == r16;
+            qxx[r] += dg ? hx : 0.0;
+            Hq[4 * r * ldh] = qux[r];
+            Uq[4 * r * ldu] = quu[r] + (dg ? hu : 0.0);
+          }
+          if (T < m) Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
+        }
         wsync();
-      }
-      WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
-      if constexpr (MC == 0)
-        for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];  // the LDS solve works in place on a copy of [Qux | Qu]
-      if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
-      wsync();
-      if constexpr (MC > 0) {
+        WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
         if (factor_solve_lane<MC>()) return true;
+        wsync();
+        WSTAMP(b3 = wstamp(); t_c += b3 - b2;)
+        {  // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
+          double p1 = 0.0, p2 = 0.0;
+          if (T < m) {
+            const double d = Kl[T * ldh + np];
+            p1 = d * Hux[T * ldh + np];
+            p2 = d * d;
+            dbig = dbig | !(fabs(d) <= 1e-9 * (1.0 + fabs(us_k)));
+          }
+          double t1 = 0.0, dd = 0.0;
+          for (int a = 0; a < m; ++a) {
+            t1 += lane_bcast(p1, a);
+            dd += lane_bcast(p2, a);
+          }
+          dV1 += t1;
+          dV2 += -0.5 * t1 - 0.5 * rho * dd;
+        }
+        // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
+        {
+          const lds_d* Hq = (const lds_d*)Hux + q4 * ldh + r16;
+          const lds_d* Kq = (const lds_d*)Kl + q4 * ldh + r16;
+          double hf[4], kf[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            hf[r] = Hq[4 * r * ldh];
+            kf[r] = Kq[4 * r * ldh];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qxx = __builtin_amdgcn_mfma_f64_16x16x4f64(hf[r], kf[r], qxx, 0, 0, 0);
+          if (rho != 0.0) {
+            d4_t kk = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kk = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[r], kf[r], kk, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qxx[r] -= rho * kk[r];
+          }
+        }
+        if (T < n) {
+          double acc = dot_lds(Hux + T, ldh, Kl + np, ldh, mp, qv[T]);  // rows >= m are zero
+          if (rho != 0.0) acc -= rho * dot_lds(Kl + T, ldh, Kl + np, ldh, mp, 0.0);
+          sv[T] = acc;
+        }
+        {  // S <- (S + S')/2 through LDS: every lane averages its four elements with their mirror images
+          lds_d* Sq = (lds_d*)S + q4 * lds + r16;
+          const lds_d* St = (const lds_d*)S + r16 * lds + q4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Sq[4 * r * lds] = qxx[r];
+          wsync();
+          double tr[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tr[r] = St[4 * r];
+          wsync();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Sq[4 * r * lds] = 0.5 * (qxx[r] + tr[r]);
+        }
       } else {
-        // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
-        for (int j = 0; j < m; ++j) {
-          const double dj = Huu[j * ldu + j];
-          if (!(dj > 0.0)) return true;  // wave-uniform
-          if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
-          wsync();
-          if (T > j && T < m) {
-            const double li = Huu[T * ldu + j];
-            for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
-          }
-          wsync();
-        }
-        // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
-        for (int c = T; c <= np; c += 64) {
-          if (c < n || c == np) {
-            for (int i = 0; i < m; ++i) {
-              double v = Kl[i * ldh + c];
-              for (int kk = 0; kk < i; ++kk) v -= Huu[i * ldu + kk] * Kl[kk * ldh + c];
-              Kl[i * ldh + c] = v;
-            }
-            for (int i = 0; i < m; ++i) Kl[i * ldh + c] /= Huu[i * ldu + i];
-            for (int i = m - 1; i >= 0; --i) {
-              double v = Kl[i * ldh + c];
-              for (int kk = i + 1; kk < m; ++kk) v -= Huu[kk * ldu + i] * Kl[kk * ldh + c];
-              Kl[i * ldh + c] = v;
-            }
-            for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
-          }
-        }
-      }
-      wsync();
-      WSTAMP(const long long b3 = wstamp(); t_c += b3 - b2;)
-      // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
-      {
-        double p1 = 0.0, p2 = 0.0;
+        // Q_z = l_z + [A B]' s
+        for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
+        WSTAMP(const long long tg = wstamp();)
+        gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
+        wsync();
+        gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
+        gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
+        gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
+        wsync();
+        if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
+        WSTAMP(t_gemm += wstamp() - tg;)
+        if (T < n) S[T * lds + T] += hz[T];
         if (T < m) {
-          const double d = Kl[T * ldh + np];
-          p1 = d * Hux[T * ldh + np];
-          p2 = d * d;
-          dbig = dbig | !(fabs(d) <= 1e-9 * (1.0 + fabs(us_k)));
+          Huu[T * ldu + T] += hz[np + T];
+          Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
         }
-        double t1 = 0.0, dd = 0.0;
-        for (int a = 0; a < m; ++a) {  // m terms in the oracle's order; v_readlane is far cheaper than a 6-step shuffle tree
-          t1 += lane_bcast(p1, a);
-          dd += lane_bcast(p2, a);
+        wsync();
+        if (Pn > 0) {
+          gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
+          gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
+          gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
+          wsync();
         }
-        dV1 += t1;
-        dV2 += -0.5 * t1 - 0.5 * rho * dd;
-      }
-      // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
-      gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
-      if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
-      if (T < n) {
-        double acc = dot_lds(Hux + T, ldh, Kl + np, ldh, mp, qv[T]);  // rows >= m are zero
-        if (rho != 0.0) acc -= rho * dot_lds(Kl + T, ldh, Kl + np, ldh, mp, 0.0);
-        sv[T] = acc;
-      }
-      wsync();
-      Walk w = start(by_n);
-      for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
-        const int i = w.q, j = w.r;
-        if (i > j) {
-          const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
-          S[i * lds + j] = v;
-          S[j * lds + i] = v;
+        WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
+        if constexpr (MC == 0)
+          for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];  // the LDS solve works in place on a copy of [Qux | Qu]
+        if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
+        wsync();
+        if constexpr (MC > 0) {
+          if (factor_solve_lane<MC>()) return true;
+        } else {
+          // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
+          for (int j = 0; j < m; ++j) {
+            const double dj = Huu[j * ldu + j];
+            if (!(dj > 0.0)) return true;  // wave-uniform
+            if (T > j && T < m) Huu[T * ldu + j] *= 1.0 / dj;
+            wsync();
+            if (T > j && T < m) {
+              const double li = Huu[T * ldu + j];
+              for (int c = j + 1; c <= T; ++c) Huu[T * ldu + c] -= li * Huu[c * ldu + j] * dj;
+            }
+            wsync();
+          }
+          // K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu: one lane per column
+          for (int c = T; c <= np; c += 64) {
+            if (c < n || c == np) {
+              for (int i = 0; i < m; ++i) {
+                double v = Kl[i * ldh + c];
+                for (int kk = 0; kk < i; ++kk) v -= Huu[i * ldu + kk] * Kl[kk * ldh + c];
+                Kl[i * ldh + c] = v;
+              }
+              for (int i = 0; i < m; ++i) Kl[i * ldh + c] /= Huu[i * ldu + i];
+              for (int i = m - 1; i >= 0; --i) {
+                double v = Kl[i * ldh + c];
+                for (int kk = i + 1; kk < m; ++kk) v -= Huu[kk * ldu + i] * Kl[kk * ldh + c];
+                Kl[i * ldh + c] = v;
+              }
+              for (int i = 0; i < m; ++i) Kl[i * ldh + c] = -Kl[i * ldh + c];
+            }
+          }
+        }
+        wsync();
+        WSTAMP(b3 = wstamp(); t_c += b3 - b2;)
+        // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
+        {
+          double p1 = 0.0, p2 = 0.0;
+          if (T < m) {
+            const double d = Kl[T * ldh + np];
+            p1 = d * Hux[T * ldh + np];
+            p2 = d * d;
+            dbig = dbig | !(fabs(d) <= 1e-9 * (1.0 + fabs(us_k)));
+          }
+          double t1 = 0.0, dd = 0.0;
+          for (int a = 0; a < m; ++a) {  // m terms in the oracle's order; v_readlane is far cheaper than a 6-step shuffle tree
+            t1 += lane_bcast(p1, a);
+            dd += lane_bcast(p2, a);
+          }
+          dV1 += t1;
+          dV2 += -0.5 * t1 - 0.5 * rho * dd;
+        }
+        // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
+        gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
+        if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
+        if (T < n) {
+          double acc = dot_lds(Hux + T, ldh, Kl + np, ldh, mp, qv[T]);  // rows >= m are zero
+          if (rho != 0.0) acc -= rho * dot_lds(Kl + T, ldh, Kl + np, ldh, mp, 0.0);
+          sv[T] = acc;
+        }
+        wsync();
+        Walk w = start(by_n);
+        for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
+          const int i = w.q, j = w.r;
+          if (i > j) {
+            const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
+            S[i * lds + j] = v;
+            S[j * lds + i] = v;
+          }
         }
       }
       double* Kk = Kgi + (size_t)k * n * m;
-      w = start(by_m);
+      Walk w = start(by_m);
       for (int e = T; e < n * m; e += 64, step(by_m, w)) Kk[e] = Kl[w.r * ldh + w.q];
       if (T < m) dgi[(size_t)k * m + T] = Kl[T * ldh + np];
       wsync();
@@ -1292,7 +1409,10 @@ struct Solver {
       }
       iters++;
       dj_zero = (dJ == 0.0) ? dj_zero + 1 : 0;
-      if (dJ < cost_tol && (confirm || todorov() < grad_tol)) break;
+      WSTAMP(const long long ttd = wstamp();)
+      const bool conv = dJ < cost_tol && (confirm || todorov() < grad_tol);
+      WSTAMP(t_td += wstamp() - ttd;)
+      if (conv) break;
       if (iters >= o.iterations) { status = ALTRO_MAX_ITERATIONS; break; }
       if (dj_zero > o.dJ_counter_limit) { status = ALTRO_NO_PROGRESS; break; }
     }
@@ -1349,19 +1469,28 @@ struct Solver {
     }
   }
 
+  // one lane's column of a [K][stride] table moved one knot down: rows (k0, k1] -> [k0, k1).  The eight loads of a
+  // chunk are issued before its first store; a plain copy loop waited a memory round trip per knot.
+  static __device__ __forceinline__ void shift_column(double* col, size_t stride, int k0, int k1) {
+    for (int k = k0; k < k1; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(k + 1 + u < k1 ? k + 1 + u : k1) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k + u < k1) col[(size_t)(k + u) * stride] = v[u];
+    }
+  }
+
   // RD.shift_fill!(Z) and Altro.shift_fill!(conSet) on plane cur (oracle orc_shift_fill)
   __device__ __forceinline__ void shift(bool primal, bool dual) {
     if (primal) {
-      double* Xs = Xp(cur);
-      double* Us = Up(cur);
-      if (T < n) for (int k = 0; k + 1 < N; ++k) Xs[(size_t)k * n + T] = Xs[(size_t)(k + 1) * n + T];
-      if (T < m) for (int k = 0; k + 2 < N; ++k) Us[(size_t)k * m + T] = Us[(size_t)(k + 1) * m + T];
+      if (T < n) shift_column(Xp(cur) + T, n, 0, N - 1);
+      if (T < m) shift_column(Up(cur) + T, m, 0, N - 2);
     }
     if (dual) {
-      for (int e = T; e < 2 * nz; e += 64)
-        for (int k = P.box_k0; k < P.box_k1; ++k) Lbi[(size_t)k * 2 * nz + e] = Lbi[(size_t)(k + 1) * 2 * nz + e];
-      if (T < Pn)
-        for (int k = P.rowk0[T]; k < P.rowk1[T]; ++k) Lci[(size_t)k * Pn + T] = Lci[(size_t)(k + 1) * Pn + T];
+      for (int e = T; e < 2 * nz; e += 64) shift_column(Lbi + e, (size_t)2 * nz, P.box_k0, P.box_k1);
+      if (T < Pn) shift_column(Lci + T, Pn, P.rowk0[T], P.rowk1[T]);
     }
     wsync();
   }
@@ -1419,7 +1548,9 @@ struct Solver {
         if (status > ALTRO_SOLVE_SUCCEEDED) break;
         if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && mu >= o.penalty_max)) break;
         if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
+        WSTAMP(const long long tdu = wstamp();)
         dual_update();
+        WSTAMP(t_du += wstamp() - tdu;)
         mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
       }
       if (status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance) status = ALTRO_SOLVE_SUCCEEDED;
@@ -1443,12 +1574,15 @@ struct Solver {
     if (Pn > 0 && P.con_static) build_static_Ac();           // and so does a time-invariant constraint table
     wsync();
     const int steps = mpc ? nsteps : 1;
+    WSTAMP(const long long trun = wstamp();)
     for (int s = 0; s < steps; ++s) {
       if (mpc) {
+        WSTAMP(const long long tsh = wstamp();)
         plant_step(first_step + s);
         kref = first_step + s + 1;  // update_trajectory!(obj, Z_track, k_mpc)
         if (mpc == 2) break;        // altro_mpc_prepare_async: new x0 only, no shift, no solve
         if (P.mpc_shift) shift(true, true);
+        WSTAMP(t_sh += wstamp() - tsh;)
       }
       solve_one();
       nsolve++;
@@ -1462,6 +1596,11 @@ struct Solver {
       P.n_rollout[inst] += nro;
 #ifdef ALTRO_WIDE_STAMPS
       P.n_trials[inst] = t_gemm;  // diagnostic build: the three counters carry cycle counts
+      t_run = wstamp() - trun;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 8] = (double)t_run;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 9] = (double)t_du;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 10] = (double)t_sh;
+      P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 11] = (double)t_td;
       P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 12] = (double)t_a;
       P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 13] = (double)t_b;
       P.Jtrace[(size_t)inst * ALTRO_TRACE_LEN + 14] = (double)t_c;
@@ -1479,10 +1618,13 @@ struct Solver {
 };
 
 // waves per SIMD the register allocator is held to, per control-size class
-constexpr int wide_waves(int MC) { return (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
+#ifndef ALTRO_WIDE_WAVES_SM
+#define ALTRO_WIDE_WAVES_SM 1
+#endif
+constexpr int wide_waves(int MC, bool SM) { return SM ? ALTRO_WIDE_WAVES_SM : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
 
 template <int MC, bool SM>
-__global__ void __launch_bounds__(64, wide_waves(MC)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
+__global__ void __launch_bounds__(64, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
   Solver<MC, SM> s(P, lds);
   s.run(mpc, first_step, nsteps);

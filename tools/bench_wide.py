@@ -76,6 +76,8 @@ if __name__ == "__main__":
     if which in ("all", "sweep"):
         for n in (16, 32, 48, 64):      # n = 8 (m = 4) runs on the 16-lane kernel
             sweep(n, 4, 50, 8192 if n <= 32 else 2048, 10)
+    if which in ("all", "horizon"):
+        sweep(12, 6, 51, 8192, 10)      # the horizon sweep's (12, 6) shape (run_random_linear.jl:80-108)
     if which in ("all", "quad"):
         quadruped(40, 2048, 8)
         quadruped(15, 2048, 8)

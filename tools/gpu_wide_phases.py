@@ -18,3 +18,4 @@ print("n=%d m=%d N=%d B=%d: %.1f ms/step; per instance-solve (Mcycles): backward
     n, m, N, B, 1e3 * dt / 4, tb.mean() / 4e6, tg.mean() / 4e6, tr.mean() / 4e6, ni.sum() / ns.sum()))
 st = altro.stats(mp.solver)
 print("   backward segments (Mcycles per instance over 4 steps): expansion %.3f  qv+gemms+rows %.3f  factor+solve %.3f  S update, gains %.3f" % tuple(st.cost_trace[:, 12 + i].mean() / 1e6 for i in range(4)))
+print("   whole run %.3f  dual updates %.3f  plant step + shift %.3f  todorov %.3f (Mcycles per instance over 4 steps)" % tuple(st.cost_trace[:, 8 + i].mean() / 1e6 for i in range(4)))

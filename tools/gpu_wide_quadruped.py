@@ -41,5 +41,6 @@ if "stamps" not in os.environ.get("ALTRO_HIP_LIB", ""):
     print("   counters per instance-solve (plain build): backward passes %.2f  rollouts %.2f  extra line-search trials %.2f" % (tb.mean() / S, tr.mean() / S, tg.mean() / S))
 st = altro.stats(mp.solver)
 print("   backward segments (Mcycles per instance over %d steps): expansion %.3f  qv+gemms+rows %.3f  factor+solve %.3f  S update, gains %.3f" % ((S,) + tuple(st.cost_trace[:, 12 + i].mean() / 1e6 for i in range(4))))
+print("   whole run %.3f  dual updates %.3f  plant step + shift %.3f  todorov %.3f (Mcycles per instance over %d steps)" % (tuple(st.cost_trace[:, 8 + i].mean() / 1e6 for i in range(4)) + (S,)))
 it = ni.astype(float)
 print("   per-instance iterations over the launch: mean %.1f p99 %.0f max %d" % (it.mean(), np.percentile(it, 99), it.max()))
