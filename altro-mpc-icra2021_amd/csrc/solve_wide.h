@@ -930,14 +930,16 @@ struct Solver {
       const double* At = AconTi + (size_t)k * nz * Pn;
       const bool resident = (P.con_static & 4) && !term;
       Walk w = start(by_P);
-      for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
-        const int j = w.q, r = w.r;
-        const int c = j < n ? j : np + (j - n);
-        const double a = resident ? Ac[r * ly.ldg + c] : ((term && j >= n) ? 0.0 : At[e]);
-        if (!resident) Ac[r * ly.ldg + c] = a;
-        DA[r * ly.ldg + c] = Dr[r] * a;
+      if (!(resident && da_on_the_fly())) {  // (otherwise the products scale the rows of Ac by Dr themselves)
+        for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
+          const int j = w.q, r = w.r;
+          const int c = j < n ? j : np + (j - n);
+          const double a = resident ? Ac[r * ly.ldg + c] : ((term && j >= n) ? 0.0 : At[e]);
+          if (!resident) Ac[r * ly.ldg + c] = a;
+          DA[r * ly.ldg + c] = Dr[r] * a;
+        }
+        wsync();
       }
-      wsync();
       if (P.ncone > 0) {  // cone rows: DA = H_block * A over the rows of the cone
         w = start(by_P);
         for (int e = T; e < nz * Pn; e += 64, step(by_P, w)) {
@@ -954,12 +956,29 @@ struct Solver {
       }
       for (int c = T; c < nzp; c += 64) {
         double acc = 0.0;
-        for (int r = 0; r < Pn; ++r) acc += Ac[r * ly.ldg + c] * gr[r];
+        if constexpr (SM) {  // four rows at a time, the eight reads ahead of the FMAs (gr is zero beyond Pn up to Pp)
+          for (int r0 = 0; r0 < Pp; r0 += 4) {
+            double a[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              a[u] = Ac[(r0 + u) * ly.ldg + c];
+              g[u] = gr[r0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += a[u] * g[u];
+          }
+        } else {
+          for (int r = 0; r < Pn; ++r) acc += Ac[r * ly.ldg + c] * gr[r];
+        }
         qz[c] += acc;
       }
       wsync();
     }
   }
+
+  // n, m <= 16, linear rows only, table resident in LDS: D A_c is never written out -- the A fragment of the products
+  // A_c' (D A_c) is the B fragment scaled by the lane's D_r
+  __device__ __forceinline__ bool da_on_the_fly() const { return SM && P.ncone == 0 && (P.con_static & 4); }
 
   // value of v on lane `lane` (wave-uniform index), to every lane: two v_readlane_b32
   static __device__ __forceinline__ double lane_bcast(double v, int lane) {
@@ -1108,8 +1127,18 @@ struct Solver {
         if (Pn > 0) {  // + A_c' diag(I_mu) A_c of the generic rows, same chains
           const lds_d* Dl = (const lds_d*)DA + q4 * ldg + r16;
           const lds_d* Al = (const lds_d*)Ac + q4 * ldg + r16;
+          const bool fly = da_on_the_fly();
           for (int r = 0; 4 * r < Pp; ++r) {  // up to 64 rows
-            const double dx = Dl[4 * r * ldg], du = Dl[4 * r * ldg + 16], ax = Al[4 * r * ldg], au = Al[4 * r * ldg + 16];
+            const double ax = Al[4 * r * ldg], au = Al[4 * r * ldg + 16];
+            double dx, du;
+            if (fly) {
+              const double dk = Dr[4 * r + q4];
+              dx = dk * ax;
+              du = dk * au;
+            } else {
+              dx = Dl[4 * r * ldg];
+              du = Dl[4 * r * ldg + 16];
+            }
             qxx = __builtin_amdgcn_mfma_f64_16x16x4f64(dx, ax, qxx, 0, 0, 0);
             qux = __builtin_amdgcn_mfma_f64_16x16x4f64(du, ax, qux, 0, 0, 0);
             quu = __builtin_amdgcn_mfma_f64_16x16x4f64(du, au, quu, 0, 0, 0);
