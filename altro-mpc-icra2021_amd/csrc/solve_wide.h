@@ -989,9 +989,9 @@ struct Solver {
 
   // Quu_reg = L D L' and K = -Quu_reg^-1 [Qux | Qu], every lane for itself (m <= MP <= 16): the lower triangle of
   // Quu_reg is read from LDS by all lanes (one broadcast read per element), factored redundantly in registers
-  // (right-looking, in place) and lane c solves for column c of [Qux | Qu].  No cross-lane traffic and no branches:
-  // rows >= m are the identity (Huu's pads are exact zeros, the diagonal is set to 1), so the unrolled MP x MP code
-  // is exact for any m <= MP.  History: the LDS version walked dependent read-modify-write chains (40 k cycles per
+  // (right-looking, in place) and lane c solves for column c of [Qux | Qu].  No cross-lane traffic, no branches, no
+  // selects: the caller leaves the identity in rows >= m of Quu_reg (the pads are exact zeros, the diagonal is set
+  // to 1) and zeros in rows >= m of [Qux | Qu], so the unrolled MP x MP code is exact for any m <= MP.  History: the LDS version walked dependent read-modify-write chains (40 k cycles per
   // knot at m = 12); a version that kept column b on lane b and handed the scalars round with v_readlane was
   // ~2800 instructions, 13 k cycles with one wave per SIMD; this one is ~900.  Returns true if a pivot is not positive.
   static __device__ __forceinline__ double rcp_nr(double x) {  // 1/x to full FP64 accuracy (x > 0, normal range)
@@ -1009,9 +1009,7 @@ struct Solver {
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
 #pragma unroll
-      for (int j = 0; j < i; ++j) a[i][j] = Hl[i * ldu + j];
-      const double dii = Hl[i * ldu + i];
-      a[i][i] = i < m ? dii : 1.0;
+      for (int j = 0; j <= i; ++j) a[i][j] = Hl[i * ldu + j];
     }
     bool fail = false;
 #pragma unroll
@@ -1036,10 +1034,7 @@ struct Solver {
       const lds_d* hc = (const lds_d*)Hux + (mine ? c : 0);
       double q[MP];
 #pragma unroll
-      for (int r = 0; r < MP; ++r) {
-        const double v = hc[r * ldh];
-        q[r] = r < m ? v : 0.0;
-      }
+      for (int r = 0; r < MP; ++r) q[r] = hc[r * ldh];
 #pragma unroll
       for (int k = 0; k < MP; ++k)          // forward: L y = b
 #pragma unroll
@@ -1052,8 +1047,7 @@ struct Solver {
         for (int i = 0; i < k; ++i) q[i] -= a[k][i] * q[k];
       if (mine) {
 #pragma unroll
-        for (int r = 0; r < MP; ++r)
-          if (r < m) Kl[r * ldh + c] = -q[r];
+        for (int r = 0; r < MP; ++r) Kl[r * ldh + c] = 0.0 - q[r];  // rows >= m: zero
       }
     }
     return false;
@@ -1146,7 +1140,7 @@ struct Solver {
         }
         WSTAMP(t_gemm += wstamp() - tg;)
         {
-          const double hx = hz[r16], hu = hz[np + r16] + (r16 < m ? rho : 0.0);  // diagonals: l_xx, l_uu + rho (bp_reg_type = :control)
+          const double hx = hz[r16], hu = hz[np + r16] + (r16 < m ? rho : 1.0);  // diagonals: l_xx, l_uu + rho (bp_reg_type = :control); identity in the pad rows
           lds_d* Hq = (lds_d*)Hux + q4 * ldh + r16;
           lds_d* Uq = (lds_d*)Huu + q4 * ldu + r16;
 #pragma unroll
@@ -1156,7 +1150,7 @@ struct Solver {
             Hq[4 * r * ldh] = qux[r];
             Uq[4 * r * ldu] = quu[r] + (dg ? hu : 0.0);
           }
-          if (T < m) Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
+          if (T < 16) Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux (zeros in the pad rows)
         }
         wsync();
         WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
@@ -1230,10 +1224,8 @@ struct Solver {
         if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
         WSTAMP(t_gemm += wstamp() - tg;)
         if (T < n) S[T * lds + T] += hz[T];
-        if (T < m) {
-          Huu[T * ldu + T] += hz[np + T];
-          Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux
-        }
+        if (T < m) Huu[T * ldu + T] += hz[np + T];
+        if (T < mp) Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux (zeros in the pad rows)
         wsync();
         if (Pn > 0) {
           gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
@@ -1245,6 +1237,7 @@ struct Solver {
         if constexpr (MC == 0)
           for (int e = T; e < mp * ldh; e += 64) Kl[e] = Hux[e];  // the LDS solve works in place on a copy of [Qux | Qu]
         if (T < m) Huu[T * ldu + T] += rho;  // bp_reg_type = :control
+        if (MC > 0 && T >= m && T < mp) Huu[T * ldu + T] = 1.0;  // factor_solve_lane: identity in the pad rows
         wsync();
         if constexpr (MC > 0) {
           if (factor_solve_lane<MC>()) return true;
