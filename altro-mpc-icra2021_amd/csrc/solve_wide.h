@@ -198,7 +198,8 @@ __device__ __forceinline__ long long wstamp() {
 template <int MC, bool SM>
 struct Solver {
   const Params& P;
-  const int T, inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
+  int T;  // lane index; made opaque again at the start of every phase (phase_begin)
+  const int inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
   const Lds ly;
   double *G, *S, *W, *Hux, *Kl, *Huu, *Ac, *DA;
   double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr, *cvv, *cll, *Hc;
@@ -270,6 +271,12 @@ struct Solver {
     if (T < m) { cwu = P.wd[n + T]; cumax = P.zmax[n + T]; cumin = P.zmin[n + T]; }
     __syncthreads();
   }
+
+  // Everything lane-dependent that a phase needs (dozens of addresses and offsets per phase) is loop-invariant for
+  // the whole kernel, and LLVM hoists all of it to the kernel's entry: more values than the 512 registers hold, so
+  // they went to scratch and every reload in a knot loop (followed by s_waitcnt vmcnt(0)) drained the operands in
+  // flight.  Making the lane index opaque at the start of a phase keeps those computations inside the phase.
+  __device__ __forceinline__ void phase_begin() { asm volatile("" : "+v"(T)); }
 
   __device__ __forceinline__ size_t dynblk(int k) const {
     return (size_t)(P.dyn_per_instance ? inst : 0) * (P.ltv ? P.dyn_blocks : 1) +
@@ -755,8 +762,251 @@ struct Solver {
     return r;
   }
 
+  // element J of v in this lane's 16-lane row (v_mov_b64_dpp row_newbcast:J)
+  template <int J>
+  static __device__ __forceinline__ double row_bcast(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);
+  }
+  // acc + sum_{j < 16} row[j] * v_j in the order j = 0..15, v_j = element j of the row vector v
+  template <int J>
+  struct RowDot {
+    static __device__ __forceinline__ double run(const double* row, double v, double acc) {
+      if constexpr (J > 1) acc = RowDot<J - 1>::run(row, v, acc);
+      return __builtin_fma(row[J - 1], row_bcast<J - 1>(v), acc);
+    }
+  };
+
+  // Rollout for n, m <= 16 with at most 16 linear rows whose table is resident (no cones): the whole knot lives in
+  // the first 16-lane row of the wave.  Lane T holds x_T and u_T, row T of K_k, of [A_k B_k] and of the constraint
+  // table in registers; the matrix-vector products take their vector operand from the other lanes with DPP
+  // row broadcasts, so a knot has no LDS hand-over and no barrier (the LDS version: three of each, ~8 k cycles per
+  // knot against the ~70 FMAs of useful work).  The terms are accumulated in the order of the LDS version, the
+  // results are bit-identical.  Lanes 16..63 carry zeros.  No branch in the knot body: every lane executes every
+  // DPP instruction (a DPP read from a disabled lane returns 0).
+  // uniform base (SGPR pair) + 32-bit per-lane element index: `global_load_dwordx2 v, v_off, s[base:base+1]`, one
+  // address VGPR per access instead of a 64-bit pointer (every per-instance array is far below 4 GiB)
+  static __device__ __forceinline__ double ldg(const double* base, unsigned idx) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+  }
+  static __device__ __forceinline__ void stg(double* base, unsigned idx, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3)) = v;
+  }
+  struct KRegs {
+    double v[4];
+  };
+
+  template <bool CLOSED, bool LTV>
+  __device__ __forceinline__ RollOut rollout_row(double alpha) {
+    // The lane index is made opaque here: everything lane-dependent below (a few dozen addresses) is then computed
+    // inside this function.  Otherwise LLVM hoists it, with the lane-dependent invariants of every other phase, to
+    // the top of the kernel -- more values than there are registers, and their reloads from scratch (each followed
+    // by s_waitcnt vmcnt(0)) sat in this loop and drained the operands in flight at every knot.
+    int t = T;
+    asm volatile("" : "+v"(t));
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    double* Xd = CLOSED ? Xp(cur ^ 1) : Xp(cur);
+    double* Ud = CLOSED ? Up(cur ^ 1) : Up(cur);
+    const bool isx = t < n, isu = t < m, isr = t < Pn, rows = Pn > 0;
+    const unsigned Tn = isx ? t : n - 1, Tm = isu ? t : m - 1, Tr = isr ? t : 0;
+    double* gtrash = P.trash + (size_t)inst * 64;  // [64]: lane t's sink is word t
+    // per-knot operands of the generic rows; a problem without rows reads (and ignores) the trash line instead
+    const int* ctp = rows ? P.ctype : (const int*)gtrash;
+    const double* lcp = rows ? Lci : gtrash;
+    const double* bcp = rows ? bconi : gtrash;
+    const unsigned rstride = rows ? (unsigned)Pn : 0u;
+    const int ldg_ = ly.ldg;
+    const unsigned nn = n * n, nm = n * m;
+    lds_d* const ltrash = (lds_d*)zb + nzp;  // LDS sink (qz[0], dead during rollouts)
+    double ac[32], ab[32];  // row t of the constraint table; row t of [A B] (time-invariant: loaded once)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const double a = Ac[Tr * ldg_ + c], g = G[Tn * ldg_ + c];
+      ac[c] = (rows & isr) ? a : 0.0;
+      ab[c] = g;
+    }
+    double fT = LTV ? 0.0 : fk(0)[Tn];
+    double J = 0.0, viol = 0.0;
+    bool lim = false, chg = false, big = false;
+    double xb = isx ? x0i[Tn] : 0.0;
+    struct Ld {
+      double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, lam, bc;
+      int ct;
+    };
+    auto ld = [&](int kk) {
+      Ld d;
+      const unsigned k = kk < N - 1 ? kk : N - 1;
+      const unsigned ku = k < (unsigned)(N - 1) ? k : N - 2;  // the terminal knot has no control: clamp, its control terms are switched off
+      d.xs = ldg(Xs, k * n + Tn);
+      d.xr = ldg(Xri, (kref + k) * n + Tn);
+      d.lxh = ldg(Lbi, (k * 2 + 0) * nz + Tn);
+      d.lxl = ldg(Lbi, (k * 2 + 1) * nz + Tn);
+      d.us = ldg(Us, ku * m + Tm);
+      d.ur = ldg(Uri, (kref + ku) * m + Tm);
+      d.luh = ldg(Lbi, (ku * 2 + 0) * nz + n + Tm);
+      d.lul = ldg(Lbi, (ku * 2 + 1) * nz + n + Tm);
+      d.dgv = CLOSED ? ldg(dgi, ku * m + Tm) : 0.0;
+      d.ct = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(ctp) + ((k * rstride + Tr) << 2));
+      d.lam = ldg(lcp, k * rstride + Tr);
+      d.bc = ldg(bcp, k * rstride + Tr);
+      return d;
+    };
+    // K_k (m x n, n m <= 256 elements) and, for per-knot dynamics, [A_k B_k f_k] travel as whole blocks: four / nine
+    // coalesced loads per lane, requested two knots ahead and parked in LDS a knot ahead (S and Huu alternate for K,
+    // W and Hux for the dynamics: all four are scratch outside the backward pass); lane t then reads its rows.
+    auto k_request = [&](int kk) {
+      const unsigned ku = kk < N - 1 ? kk : N - 2;
+      KRegs r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        r.v[u] = CLOSED ? ldg(Kgi, ku * nm + (e < nm ? e : nm - 1)) : 0.0;
+      }
+      return r;
+    };
+    auto k_park = [&](const KRegs& r, lds_d* st) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        *(e < nm ? st + e : ltrash) = r.v[u];
+      }
+    };
+    auto dyn_req = [&](int k) {
+      const double *A_ = Ak(k), *B_ = Bk(k);
+      DynRegs q;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        q.a[u] = ldg(A_, e < nn ? e : nn - 1);
+        q.b[u] = ldg(B_, e < nm ? e : nm - 1);
+      }
+      q.f = ldg(fk(k), Tn);
+      return q;
+    };
+    auto dyn_park = [&](const DynRegs& q, lds_d* st) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        *(e < nn ? st + e : ltrash) = q.a[u];
+        *(e < nm ? st + nn + e : ltrash) = q.b[u];
+      }
+      *(isx ? st + nn + nm + t : ltrash) = q.f;
+    };
+    // The per-lane operands are requested THREE knots ahead: a knot is ~1.5 k cycles of arithmetic, a round trip to
+    // HBM ~4 k, and the wave has the SIMD to itself -- with one knot of lookahead every knot waited for memory.
+    // The loop body is one basic block (no branch: hipcc waits vmcnt(0) after a join), so the waits are counted.
+    lds_d* const park[2] = {(lds_d*)W, (lds_d*)Hux};
+    lds_d* const kpark[2] = {(lds_d*)S, (lds_d*)Huu};
+    DynRegs dq0 = {}, dq1 = {};
+    KRegs kq0 = k_request(0), kq1 = k_request(1);
+    k_park(kq0, kpark[0]);
+    kq0 = kq1;
+    if (LTV) {
+      dq0 = dyn_req(0);
+      dq1 = dyn_req(N > 2 ? 1 : 0);
+      dyn_park(dq0, park[0]);
+      dq0 = dq1;  // block 1, parked at the end of knot 0
+    }
+    Ld d = ld(0), d1 = ld(1), d2 = ld(2);
+    wsync();
+    for (int k = 0; k < N - 1; ++k) {
+      const Ld d3 = ld(k + 3);
+      kq1 = k_request(k + 2);
+      double kp[16];
+      if constexpr (CLOSED) {
+        const lds_d* st = kpark[k & 1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kp[j] = st[(j < n ? j : n - 1) * m + Tm];
+      }
+      if constexpr (LTV) {  // row t of this knot's block (parked a knot ago); block k + 2 on its way
+        const lds_d* st = park[k & 1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          ab[j] = st[Tn + n * (j < n ? j : n - 1)];
+          ab[16 + j] = st[nn + Tn + n * (j < m ? j : m - 1)];
+        }
+        fT = st[nn + nm + Tn];
+        dq1 = dyn_req(k + 2 < N - 1 ? k + 2 : N - 2);
+      }
+      const bool bx = box_at(k);
+      *(isx ? Xd + (unsigned)k * n + t : gtrash + t) = xb;
+      double uv = d.us;
+      if (CLOSED) {
+        const double dx = isx ? xb - d.xs : 0.0;
+        uv += alpha * d.dgv;
+        uv = RowDot<16>::run(kp, dx, uv);
+        *(isu ? Ud + (unsigned)k * m + t : gtrash + t) = uv;
+      }
+      uv = isu ? uv : 0.0;
+      if (CLOSED) {
+        chg = chg | (isx & (xb != d.xs)) | (isu & (uv != d.us));
+        big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs)))) | (isu & !(fabs(uv - d.us) <= 1e-7 * (1.0 + fabs(d.us))));
+      }
+      J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
+      J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
+      {  // generic rows: value, AL cost, violation
+        double v = RowDot<16>::run(ac, xb, d.bc);
+        v = RowDot<16>::run(ac + 16, uv, v);
+        const bool on = isr & (d.ct != 0), eq = d.ct == 1;
+        const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+        const double cj = d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
+        J += on ? cj : 0.0;
+        viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
+      }
+      lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
+      double xn = RowDot<16>::run(ab, xb, fT);
+      xn = RowDot<16>::run(ab + 16, uv, xn);
+      k_park(kq0, kpark[(k & 1) ^ 1]);  // block k + 1
+      kq0 = kq1;
+      if constexpr (LTV) {
+        dyn_park(dq0, park[(k & 1) ^ 1]);
+        dq0 = dq1;
+      }
+      wsync();
+      xb = isx ? xn : 0.0;
+      d = d1;
+      d1 = d2;
+      d2 = d3;
+    }
+    *(isx ? Xd + (unsigned)(N - 1) * n + t : gtrash + t) = xb;
+    J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
+    {  // rows of the terminal knot see the state only
+      const double v = RowDot<16>::run(ac, xb, d.bc);
+      const bool on = isr & (d.ct != 0), eq = d.ct == 1;
+      const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+      const double cj = d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
+      J += on ? cj : 0.0;
+      viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
+    }
+    lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));
+    if (CLOSED) {
+      chg = chg | (isx & (xb != d.xs));
+      big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
+    }
+    __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
+    RollOut r;
+    r.J = wave_sum(J);
+    r.cmax = wave_max(viol);
+    r.limit = wave_any(lim);
+    r.unchanged = CLOSED && !wave_any(chg);
+    r.tiny = CLOSED && !wave_any(big);
+    return r;
+  }
+
+  __device__ __forceinline__ bool row_rollouts() const {
+    return SM && P.ncone == 0 && Pn <= 16 && (Pn == 0 || (P.con_static & 1));
+  }
+
   __device__ __forceinline__ RollOut rollout(bool open, double alpha) {
-    if (Pn == 0 && !P.ltv) return open ? rollout_simple<false>(0.0) : rollout_simple<true>(alpha);
+    phase_begin();
+    if constexpr (SM) {
+      if (row_rollouts()) {
+        if (P.ltv) return open ? rollout_row<false, true>(0.0) : rollout_row<true, true>(alpha);
+        return open ? rollout_row<false, false>(0.0) : rollout_row<true, false>(alpha);
+      }
+    } else {
+      if (Pn == 0 && !P.ltv) return open ? rollout_simple<false>(0.0) : rollout_simple<true>(alpha);
+    }
     return rollout_generic(open, alpha);
   }
 
@@ -1055,6 +1305,7 @@ struct Solver {
 
   // backwardpass! (oracle backward_pass).  Returns true if a pivot of Quu + rho I was not positive.
   __device__ __forceinline__ bool backward(double& dV1, double& dV2) {
+    phase_begin();
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
@@ -1443,6 +1694,7 @@ struct Solver {
 
   // dual_update! on plane cur (the penalty is scaled by the caller)
   __device__ __forceinline__ void dual_update() {
+    phase_begin();
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     const double dmax = P.o.dual_max;
@@ -1506,6 +1758,7 @@ struct Solver {
 
   // RD.shift_fill!(Z) and Altro.shift_fill!(conSet) on plane cur (oracle orc_shift_fill)
   __device__ __forceinline__ void shift(bool primal, bool dual) {
+    phase_begin();
     if (primal) {
       if (T < n) shift_column(Xp(cur) + T, n, 0, N - 1);
       if (T < m) shift_column(Up(cur) + T, m, 0, N - 2);
@@ -1519,6 +1772,7 @@ struct Solver {
 
   // plant step of the device MPC loop: x0 <- A x_1 + B u_1 + f + noise (time-invariant dynamics only)
   __device__ __forceinline__ void plant_step(int step) {
+    phase_begin();
     const double* Xs = Xp(cur);
     const double* Us = Up(cur);
     if (T < n) zb[T] = Xs[T];
@@ -1557,26 +1811,27 @@ struct Solver {
     iters_outer = 0;
     __syncthreads();  // the zeroed duals are read by other lanes
     double J = 0.0, cmax = 0.0;
-    if (!has_con) {
-      J = ilqr(o.cost_tolerance, o.gradient_tolerance, cmax);
-      cmax = 0.0;
-      if (status == ALTRO_UNSOLVED) status = ALTRO_SOLVE_SUCCEEDED;
-    } else {
-      for (int jo = 0; jo < o.iterations_outer; ++jo) {
-        const bool last = jo == o.iterations_outer - 1;
-        J = ilqr(last ? o.cost_tolerance : o.cost_tolerance_intermediate,
-                 last ? o.gradient_tolerance : o.gradient_tolerance_intermediate, cmax);
-        iters_outer++;
-        if (status > ALTRO_SOLVE_SUCCEEDED) break;
-        if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && mu >= o.penalty_max)) break;
-        if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
-        WSTAMP(const long long tdu = wstamp();)
-        dual_update();
-        WSTAMP(t_du += wstamp() - tdu;)
-        mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
+    // one call site for ilqr(): the whole iLQR (rollouts, backward pass) is inlined into it
+    const int nouter = has_con ? o.iterations_outer : 1;
+    for (int jo = 0; jo < nouter; ++jo) {
+      const bool last = jo == nouter - 1;
+      J = ilqr(last ? o.cost_tolerance : o.cost_tolerance_intermediate,
+               last ? o.gradient_tolerance : o.gradient_tolerance_intermediate, cmax);
+      if (!has_con) {
+        cmax = 0.0;
+        if (status == ALTRO_UNSOLVED) status = ALTRO_SOLVE_SUCCEEDED;
+        break;
       }
-      if (status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance) status = ALTRO_SOLVE_SUCCEEDED;
+      iters_outer++;
+      if (status > ALTRO_SOLVE_SUCCEEDED) break;
+      if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && mu >= o.penalty_max)) break;
+      if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
+      WSTAMP(const long long tdu = wstamp();)
+      dual_update();
+      WSTAMP(t_du += wstamp() - tdu;)
+      mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
     }
+    if (has_con && status <= ALTRO_SOLVE_SUCCEEDED && cmax < o.constraint_tolerance) status = ALTRO_SOLVE_SUCCEEDED;
     if (T == 0) {
       P.cost[inst] = J;
       P.cmax[inst] = cmax;
