@@ -452,6 +452,13 @@ struct Solver {
     return c;
   }
 
+  // Everything lane-dependent a phase needs (a few dozen addresses: the Gcol columns, the dual rows, the gain rows) is
+  // loop-invariant for the whole kernel; LLVM hoists all of it to the kernel's entry, where it does not fit the 256
+  // registers, and every phase then opened with a chain of `scratch_load address; s_waitcnt vmcnt(0); global_load`
+  // -- two dozen memory round trips in series before a rollout's first knot.  Making the lane's indices opaque at the
+  // start of a phase keeps those computations (a handful of integer instructions) inside the phase.
+  __device__ __forceinline__ void phase_begin() { asm volatile("" : "+v"(j), "+v"(rowoff), "+v"(lslot), "+v"(inst)); }
+
   __device__ __forceinline__ unsigned at(int k) const { return (unsigned)k * kstride + rowoff; }
   // plane c of Z as an element offset (per instance: cur differs between rows)
   __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * kstride; }
@@ -551,6 +558,7 @@ struct Solver {
   //          storeq: rows whose gradient plane Qz this rollout refreshes (the rows that are searching).
   template <bool OPEN>
   __device__ RollOut rollout(bool take, bool shift, bool storeq = false) {
+    phase_begin();
     prio_serial();  // latency-bound phase: see ALTRO_PRIO_SERIAL
     const LaneConst lc = consts();
     const double mu = rs->mu;
@@ -777,6 +785,7 @@ struct Solver {
   // gradient_todorov!: mean_k max_a |d_k,a| / (|u_k,a| + 1) on the current plane.  Evaluated
   // lazily: the reference only uses it in the convergence test, which also needs dJ < tol.
   __device__ double todorov() {
+    phase_begin();
     prio_serial();
     const unsigned zs = plane(rs->cur);
     const int N = P.N;
@@ -818,6 +827,7 @@ struct Solver {
   };
 
   __device__ void trial_costs(double alpha, Trials& T) {
+    phase_begin();
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const int cur = rs->cur, kref = rs->kref;
@@ -902,6 +912,7 @@ struct Solver {
 
   // Z̄ <- Z + alpha (Z̄(1) - Z) in plane cur^1, for the rows flagged `doit`
   __device__ void interpolate(double alpha, bool doit) {
+    phase_begin();
     const int cur = rs->cur;
     const unsigned zs = plane(cur);
     const unsigned z1 = plane(cur ^ 1);
@@ -963,6 +974,7 @@ struct Solver {
   // "confirmation iteration" shortcut in run().
   template <bool RHO, bool SYM>
   __device__ void backward(double& dV1, double& dV2, bool& fail, bool& dtiny, bool live) {
+    phase_begin();
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const double rho = RHO ? rs->rho : 0.0;
@@ -1196,6 +1208,7 @@ struct Solver {
   // pass vanishes iff every g_k does, and |d_k| <= |g_k|_2 / lambda_min(Quu) <= 2 |g_k|_inf / (dt R):
   // gtiny (out) says |g_k,a| <= 0.25e-9 dt R_a at every knot, i.e. |d| <= 0.5e-9.
   __device__ void adjoint(bool& gtiny) {
+    phase_begin();
     prio_serial();
     double g[NX];
     sfor<0, NX>([&](auto c) {
@@ -1229,6 +1242,7 @@ struct Solver {
 
   // dual_update! for the box rows of plane `cur` (penalty_update! is the caller's mu *= phi)
   __device__ void dual_update(bool upd) {
+    phase_begin();
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const unsigned zs = plane(rs->cur);
@@ -1263,6 +1277,7 @@ struct Solver {
   // Plant step of the MPC loop (random_linear_problem.jl:128-130) for the rows flagged `doit`:
   //   x0 <- A x_1 + B u_1 + f + randn(n) * ||x0||_inf / 100
   __device__ void plant_step(bool doit, int step) {
+    phase_begin();
     double grow[NZ];
     sfor<0, NZ>([&](auto c) {
       constexpr int C = decltype(c)::value;
