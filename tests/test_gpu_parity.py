@@ -40,6 +40,82 @@ def check_against_oracle(st, X, U, b, orc, so, utol=RTOL, ttol=RTOL, jtol=RTOL):
     assert rel_err(U[b], orc.controls()) <= utol
 
 
+@pytest.mark.parametrize("n,m,N", [(16, 4, 50), (12, 6, 31), (20, 4, 21)])
+def test_wide_kernel_strict_option_and_default_shortcuts(oracle, n, m, N):
+    """The one-wave-per-instance kernel takes the default-mode shortcuts of the 16-lane kernels (confirmation
+    iterations when every feedforward term is at rounding level, the line-search early-outs: solve_wide.h ilqr());
+    altro_opts.strict = 1 runs every iteration in full.  (16,4), (12,6): the n, m <= 16 instantiation (products chained
+    in registers, DPP row rollouts); (20,4): the generic one.
+    (a) strict against the oracle, accepted steps included wherever the iteration moved;
+    (b) default against strict over a closed loop: same statuses, iteration counts equal in all but a sliver of
+        solves, closed-loop states and controls within 1e-6 -- and fewer rollouts (the point of the shortcuts)."""
+    B, S = 5, 4
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=31)
+    mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(strict=1, **REF_OPTS))
+    assert altro.wave_cycles(mp.solver).size == 0        # wide path
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    for o in orcs:
+        o.solve()
+    for i in range(S):
+        mp.step(i)
+        st, X, U, at = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), altro.alpha_trace(mp.solver)
+        for b, o in enumerate(orcs):
+            mpc_update(o, pb, b, i)
+            so = o.solve()
+            check_against_oracle(st, X, U, b, o, so)
+            k = min(so.iterations, at.shape[1])
+            Jt = np.array(so.J[:k])
+            moved = np.r_[True, np.abs(np.diff(Jt)) > 1e-9 * np.maximum(1.0, np.abs(Jt[1:]))]
+            assert np.array_equal(at[b, :k][moved], np.array(so.alpha[:k])[moved]), (i, b, at[b, :k], list(so.alpha[:k]))
+    B, S = 128, 30
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=32)
+    runs = []
+    for strict in (0, 1):
+        mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(strict=strict, **REF_OPTS))
+        mp.initial_solve()
+        altro.timing_reset(mp.solver)
+        x0s, u1s, its, sts = [], [], [], []
+        for i in range(S):
+            mp.step(i)
+            st = altro.stats(mp.solver)
+            x0s.append(mp.x0()); u1s.append(altro.controls(mp.solver)[:, 0].copy()); its.append(st.iterations.copy()); sts.append(st.status.copy())
+        nb, nr, ntr = altro.work_counters(mp.solver)
+        runs.append((np.array(x0s), np.array(u1s), np.array(its), np.array(sts), float((nr + ntr).sum())))
+    (xa, ua, ia, sa, ra), (xb, ub, ib, sb, rb) = runs
+    assert np.array_equal(sa, sb) and np.all(sa == altro.SOLVE_SUCCEEDED)
+    assert (ia != ib).mean() <= 5e-3, (ia != ib).mean()
+    assert rel_err(xa, xb) <= RTOL and rel_err(ua, ub) <= RTOL, (rel_err(xa, xb), rel_err(ua, ub))
+    assert ra < 0.8 * rb, (ra, rb)
+    print("wide kernel (%d,%d), strict vs default over %d x %d solves: iteration counts differ in %.3f %%, x0 %.1e, u1 %.1e; rollouts %.0f vs %.0f" % (
+        n, m, B, S, 100 * (ia != ib).mean(), rel_err(xa, xb), rel_err(ua, ub), rb, ra))
+
+
+def test_wide_kernel_quadruped_strict_equals_default():
+    """Per-knot dynamics and friction pyramids (the DPP row rollouts with parked blocks): five device-resident ticks at
+    strict = 1 and in the default mode end in the same statuses and iteration counts and within 1e-6 of each other."""
+    B, S, N = 64, 5, 15
+    qp = P.gen_quadruped_problem(N=N)
+    rng = np.random.default_rng(27)
+    t0 = rng.uniform(0.0, 0.8, B)
+    x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+    A, Bm, d = _quadruped_track(qp, t0, S + N)
+    noise = rng.standard_normal((S, B, 12))
+    out = []
+    for strict in (0, 1):
+        mp = _quadruped_device_loop(qp, x0, A, Bm, d, noise, S, strict=strict)
+        mp.initial_solve()
+        its = [altro.stats(mp.solver).iterations.copy()]
+        for i in range(S):
+            mp.step(i)
+            its.append(altro.stats(mp.solver).iterations.copy())
+        out.append((np.array(its), altro.stats(mp.solver).status.copy(), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()))
+    (ia, sa, Xa, Ua, xa), (ib, sb, Xb, Ub, xb) = out
+    assert np.array_equal(sa, sb)
+    assert (ia != ib).mean() <= 1e-2, (ia != ib).mean()
+    assert rel_err(Xa, Xb) <= RTOL and rel_err(Ua, Ub) <= RTOL and rel_err(xa, xb) <= RTOL
+
+
 @pytest.mark.parametrize("n,m,N", [(12, 4, 50), (6, 3, 21), (6, 6, 31), (8, 4, 11)])
 def test_mpc_loop_matches_oracle(oracle, n, m, N):
     """Warm-started MPC loop (reference run_MPC order) for every built kernel size."""
@@ -159,12 +235,12 @@ def _quadruped_track(qp, t0, nblocks):
     return np.stack([a for a, _, _ in D]), np.stack([bm for _, bm, _ in D]), np.stack([dd for _, _, dd in D])
 
 
-def _quadruped_device_loop(qp, x0, A, Bm, d, noise, steps):
+def _quadruped_device_loop(qp, x0, A, Bm, d, noise, steps, **more_opts):
     """TrackMPC over the quadruped problem with the dynamics of every tick resident on the device"""
     B, N = x0.shape[0], qp.N
     Nt = steps + N + 1
     prob = quadruped_gpu_problem(altro, qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
-    mp = altro.mpc.TrackMPC(prob, altro.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
+    mp = altro.mpc.TrackMPC(prob, altro.SolverOptions(**dict(P.QUADRUPED_OPTS, **more_opts)), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
                             noise, (np.full(12, 1e-3),))
     altro.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
     altro.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))      # set_track installed the track's zeros
