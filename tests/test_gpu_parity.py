@@ -1156,6 +1156,47 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
+@pytest.mark.parametrize("N", [3, 4, 5, 6])
+def test_wide_kernel_shortest_horizons(oracle, monkeypatch, N):
+    """Horizons of 3..6 knots (3 is the ABI's minimum) on the one-wave-per-instance kernel, time-invariant and per-knot dynamics: the row
+    rollouts request their operands up to three knots ahead and the dynamics / gain blocks two knots ahead, so every
+    clamp at the end of the horizon is exercised (sizes (3,2), (12,4) via ALTRO_FORCE_WIDE, and (16,4))."""
+    monkeypatch.setenv("ALTRO_FORCE_WIDE", "1")
+    for n, m in ((3, 2), (12, 4), (16, 4)):
+        B, S = 4, 3
+        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=40 + N)
+        mp = altro.mpc.BatchMPC(pb)
+        assert altro.wave_cycles(mp.solver).size == 0
+        mp.initial_solve()
+        orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+        sos = [o.solve() for o in orcs]
+        st, X, U = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver)
+        for b in range(B):
+            check_against_oracle(st, X, U, b, orcs[b], sos[b])
+        for i in range(S):
+            mp.step(i)
+            st, X, U = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver)
+            for b in range(B):
+                mpc_update(orcs[b], pb, b, i)
+                check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+        # per-knot dynamics on the same sizes
+        rng = np.random.default_rng(50 + N)
+        A = pb.A[:, None] * (1.0 + 0.1 * rng.standard_normal((N - 1, 1, 1)))[None]
+        Bm = pb.Bm[:, None] * (1.0 + 0.1 * rng.standard_normal((N - 1, 1, 1)))[None]
+        d = 0.05 * rng.standard_normal((B, N - 1, n))
+        prob = altro.mpc.gen_tracking_problem(pb)
+        prob.model = altro.LinearModel(A, Bm, d, dt=pb.dt, per_knot=True)
+        prob.x0 = prob.x0 + rng.standard_normal(prob.x0.shape)
+        sv = altro.ALTROSolver(prob, altro.SolverOptions(**REF_OPTS))
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            o = make_oracle(oracle, pb, b)
+            o.set_dynamics(A[b], Bm[b], d[b])
+            o.set_initial_state(prob.x0[b])
+            check_against_oracle(st, X, U, b, o, o.solve())
+
+
 @pytest.mark.parametrize("n,m", [(12, 4), (12, 3), (8, 4), (6, 6), (6, 3), (12, 6), (20, 9)])
 def test_option_fuzz_matches_oracle(oracle, n, m):
     """Random solver options on random problems, cold starts far from the reference: iteration caps that end
