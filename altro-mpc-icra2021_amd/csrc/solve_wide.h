@@ -71,7 +71,7 @@ __host__ __device__ inline int pad4(int v) { return (v + 3) & ~3; }
 
 // LDS carve-up (offsets in doubles)
 struct Lds {
-  int G, S, W, Hux, Kl, Huu, Ac, DA, vec, total;
+  int G, S, W, Hux, Kl, Huu, Ac, DA, vec, cmd, total;
   int ldg, lds, ldh, ldu;
 };
 __host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
@@ -91,6 +91,7 @@ __host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
   L.Ac = o; o += Pp * L.ldg;
   L.DA = o; o += Pp * L.ldg;
   L.vec = o; o += 6 * nzp + 2 * np + 8 * (Pp + 4);
+  L.cmd = o; o += 32;  // command block of the cooperative products (CoopCmd)
   L.total = o;
   return L;
 }
@@ -102,6 +103,14 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// phase end inside the solver wave: every global store of the phase has completed and is visible to the other
+// lanes (__syncthreads() minus the s_barrier: the helper waves of a cooperative block do not take part)
+__device__ __forceinline__ void block_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -155,20 +164,80 @@ __device__ __forceinline__ void gemm_strip(lds_d* C, int ldc, const lds_d* ap, i
     }
 }
 
+// one strip of 16 output rows: Cl, Al, Bl already point at this lane's element of the strip's first tile
+template <bool ACC>
+__device__ __forceinline__ void gemm_rows(lds_d* Cl, int ldc, const lds_d* Al, int lda, const lds_d* Bl, int ldb, int Nn, int K, double scale) {
+  int j0 = 0;
+  for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  const int rem = (Nn - j0) >> 4;
+  if (rem == 3) gemm_strip<ACC, 3>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  else if (rem == 2) gemm_strip<ACC, 2>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  else if (rem == 1) gemm_strip<ACC, 1>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+}
+
 template <bool ACC>
 __device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, int lda, const double* Bq, int ldb, int M,
                                         int Nn, int K, double scale = 1.0) {
-  const int l = threadIdx.x, r16 = l & 15, q = l >> 4;
+  const int l = threadIdx.x & 63, r16 = l & 15, q = l >> 4;
   lds_d* Cl = (lds_d*)C + q * ldc + r16;
   const lds_d* Al = (const lds_d*)AT + q * lda + r16;
   const lds_d* Bl = (const lds_d*)Bq + q * ldb + r16;
-  for (int i0 = 0; i0 < M; i0 += 16) {
-    int j0 = 0;
-    for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
-    const int rem = (Nn - j0) >> 4;
-    if (rem == 3) gemm_strip<ACC, 3>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
-    else if (rem == 2) gemm_strip<ACC, 2>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
-    else if (rem == 1) gemm_strip<ACC, 1>(Cl + i0 * ldc + j0, ldc, Al + i0, lda, Bl + j0, ldb, K, scale);
+  for (int i0 = 0; i0 < M; i0 += 16) gemm_rows<ACC>(Cl + i0 * ldc, ldc, Al + i0, lda, Bl, ldb, Nn, K, scale);
+}
+
+// ---- cooperative products: a block of four waves per instance --------------------------------------------------
+// With n >= 48 the LDS carve-up leaves room for ONE instance per CU, i.e. one wave on one of the CU's four SIMDs,
+// and the knot's large products (W = S [A B], Qxx = A' W, S += Qux' K: 64 x 64 x 64 at n = 64) ran on that SIMD's
+// matrix pipe alone.  Such problems are launched with 256 threads: wave 0 is the solver, waves 1..3 wait at a
+// barrier for a command in LDS -- a list of products, or the symmetrisation of S -- take their share of the 16-row
+// strips, and wait again.  Every command is two s_barrier for all four waves; wave 0 sends QUIT when it is done.
+struct GemmDesc {
+  int C, ldc, A, lda, B, ldb, M, Nn, K, acc, rot, pad;  // operands as offsets (doubles) from the LDS base
+  double scale;
+};
+struct CoopCmd {
+  int op, ng;  // op: 0 quit, 1 products, 2 S <- (S + S')/2 (g[0].C, g[0].ldc, g[0].M = n)
+  GemmDesc g[3];
+};
+constexpr int kCoopQuit = 0, kCoopGemm = 1, kCoopSym = 2;
+
+__device__ __forceinline__ void coop_exec(double* lds, const CoopCmd* c, int wv, int nw) {
+  const int l = threadIdx.x & 63, r16 = l & 15, q = l >> 4;
+  if (c->op == kCoopGemm) {
+    for (int g = 0; g < c->ng; ++g) {
+      const GemmDesc d = c->g[g];
+      lds_d* Cl = (lds_d*)lds + d.C + q * d.ldc + r16;
+      const lds_d* Al = (const lds_d*)lds + d.A + q * d.lda + r16;
+      const lds_d* Bl = (const lds_d*)lds + d.B + q * d.ldb + r16;
+      for (int st = 0; 16 * st < d.M; ++st) {
+        if (((st + d.rot) & (nw - 1)) != wv) continue;  // strips of descriptors that accumulate into the same C keep their wave
+        if (d.acc) gemm_rows<true>(Cl + 16 * st * d.ldc, d.ldc, Al + 16 * st, d.lda, Bl, d.ldb, d.Nn, d.K, d.scale);
+        else gemm_rows<false>(Cl + 16 * st * d.ldc, d.ldc, Al + 16 * st, d.lda, Bl, d.ldb, d.Nn, d.K, d.scale);
+      }
+    }
+  } else if (c->op == kCoopSym) {
+    lds_d* Sl = (lds_d*)lds + c->g[0].C;
+    const int ld = c->g[0].ldc, nn = c->g[0].M;
+    for (int i = wv; i < nn; i += nw)
+      for (int j = l; j < i; j += 64) {
+        const double v = 0.5 * (Sl[i * ld + j] + Sl[j * ld + i]);
+        Sl[i * ld + j] = v;
+        Sl[j * ld + i] = v;
+      }
+  }
+}
+
+__device__ __forceinline__ void coop_barrier() { __syncthreads(); }
+
+// waves 1..3 of a cooperative block
+__device__ __forceinline__ void coop_helper(double* lds, int cmd_off) {
+  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const CoopCmd* slot = (const CoopCmd*)(lds + cmd_off);
+  while (true) {
+    __syncthreads();
+    if (slot->op == kCoopQuit) break;
+    coop_exec(lds, slot, wv, nw);
+    __syncthreads();
   }
 }
 
@@ -203,6 +272,7 @@ struct Solver {
   const Lds ly;
   double *G, *S, *W, *Hux, *Kl, *Huu, *Ac, *DA;
   double *zb, *dxv, *sv, *qz, *hz, *qv, *gr, *Dr, *cvv, *cll, *Hc;
+  double* lds_base;
   int myc0 = 0, mycp = 0;
   // e = T + 64 t written as q * d + r without a division per element (an integer division is ~40
   // VALU instructions, and the element loops below ran one per 64 elements per knot): the lane's
@@ -247,6 +317,7 @@ struct Solver {
   __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
         nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn)) {
+    lds_base = lds;
     G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
     Ac = lds + ly.Ac; DA = lds + ly.DA;
     double* v = lds + ly.vec;
@@ -269,7 +340,7 @@ struct Solver {
     for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
     if (T < n) { cwx = P.wd[T]; cwfx = P.wf[T]; cxmax = P.zmax[T]; cxmin = P.zmin[T]; }
     if (T < m) { cwu = P.wd[n + T]; cumax = P.zmax[n + T]; cumin = P.zmin[n + T]; }
-    __syncthreads();
+    block_sync();
   }
 
   // Everything lane-dependent that a phase needs (dozens of addresses and offsets per phase) is loop-invariant for
@@ -277,6 +348,38 @@ struct Solver {
   // they went to scratch and every reload in a knot loop (followed by s_waitcnt vmcnt(0)) drained the operands in
   // flight.  Making the lane index opaque at the start of a phase keeps those computations inside the phase.
   __device__ __forceinline__ void phase_begin() { asm volatile("" : "+v"(T)); }
+
+  // cooperative block (four waves, see coop_exec): wave 0 posts a command for the helper waves and takes its share
+  __device__ __forceinline__ bool coop_on() const { return !SM && blockDim.x > 64; }
+  __device__ __forceinline__ GemmDesc gdesc(bool acc, const double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int Nn,
+                                            int K, double scale, int rot) const {
+    GemmDesc d;
+    d.C = (int)(C - lds_base); d.ldc = ldc;
+    d.A = (int)(A - lds_base); d.lda = lda;
+    d.B = (int)(B - lds_base); d.ldb = ldb;
+    d.M = M; d.Nn = Nn; d.K = K; d.acc = acc ? 1 : 0; d.rot = rot; d.pad = 0; d.scale = scale;
+    return d;
+  }
+  __device__ __forceinline__ void coop_run(int op, int ng, const GemmDesc& g0, const GemmDesc& g1, const GemmDesc& g2) {
+    CoopCmd* slot = (CoopCmd*)(lds_base + ly.cmd);
+    if (T == 0) {
+      slot->op = op;
+      slot->ng = ng;
+      slot->g[0] = g0;
+      slot->g[1] = g1;
+      slot->g[2] = g2;
+    }
+    coop_barrier();
+    coop_exec(lds_base, slot, 0, (int)(blockDim.x >> 6));
+    coop_barrier();
+  }
+  __device__ __forceinline__ void coop_quit() {
+    if (coop_on()) {
+      CoopCmd* slot = (CoopCmd*)(lds_base + ly.cmd);
+      if (T == 0) slot->op = kCoopQuit;
+      coop_barrier();
+    }
+  }
 
   __device__ __forceinline__ size_t dynblk(int k) const {
     return (size_t)(P.dyn_per_instance ? inst : 0) * (P.ltv ? P.dyn_blocks : 1) +
@@ -752,7 +855,7 @@ struct Solver {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
     }
-    __syncthreads();
+    block_sync();
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
@@ -983,7 +1086,7 @@ struct Solver {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
     }
-    __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
+    block_sync();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
@@ -1077,7 +1180,7 @@ struct Solver {
       chg = chg | (T < n && xb != d.xs);
       big = big | (T < n && !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
     }
-    __syncthreads();  // phase end: the trajectory written to global memory is read by other lanes next
+    block_sync();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
     r.J = wave_sum(J);
     r.cmax = wave_max(viol);
@@ -1466,12 +1569,21 @@ struct Solver {
         // Q_z = l_z + [A B]' s
         for (int c = T; c < nzp; c += 64) qv[c] = dot_lds(G + c, ldg, sv, 1, np, qz[c]);  // rows >= n of G and sv are zero
         WSTAMP(const long long tg = wstamp();)
-        gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
-        wsync();
-        gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
-        gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
-        gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
-        wsync();
+        const bool coop = coop_on();
+        const GemmDesc g_none = {};
+        if (coop) {
+          coop_run(kCoopGemm, 1, gdesc(false, W, ldg, S, lds, G, ldg, np, nzp, np, 1.0, 0), g_none, g_none);  // W = S [A B]
+          coop_run(kCoopGemm, 3, gdesc(false, Hux, ldh, G + np, ldg, W, ldg, mp, np, np, 1.0, 0),           // Qux = B' S A
+                   gdesc(false, Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np, 1.0, 1),                    // Quu = B' S B
+                   gdesc(false, S, lds, G, ldg, W, ldg, np, np, np, 1.0, 2));                               // Qxx = A' S A
+        } else {
+          gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
+          wsync();
+          gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
+          gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
+          gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
+          wsync();
+        }
         if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
         WSTAMP(t_gemm += wstamp() - tg;)
         if (T < n) S[T * lds + T] += hz[T];
@@ -1479,10 +1591,15 @@ struct Solver {
         if (T < mp) Hux[T * ldh + np] = qv[np + T];  // Qu rides as column np of Qux (zeros in the pad rows)
         wsync();
         if (Pn > 0) {
-          gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
-          gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
-          gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
-          wsync();
+          if (coop) {
+            coop_run(kCoopGemm, 3, gdesc(true, Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp, 1.0, 0),
+                     gdesc(true, Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp, 1.0, 1), gdesc(true, S, lds, DA, ldg, Ac, ldg, np, np, Pp, 1.0, 2));
+          } else {
+            gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
+            gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
+            gemm_tn<true>(Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp);
+            wsync();
+          }
         }
         WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
         if constexpr (MC == 0)
@@ -1543,21 +1660,30 @@ struct Solver {
           dV2 += -0.5 * t1 - 0.5 * rho * dd;
         }
         // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
-        gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
-        if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
-        if (T < n) {
-          double acc = dot_lds(Hux + T, ldh, Kl + np, ldh, mp, qv[T]);  // rows >= m are zero
-          if (rho != 0.0) acc -= rho * dot_lds(Kl + T, ldh, Kl + np, ldh, mp, 0.0);
-          sv[T] = acc;
+        if (coop) {
+          coop_run(kCoopGemm, rho != 0.0 ? 2 : 1, gdesc(true, S, lds, Hux, ldh, Kl, ldh, np, np, mp, 1.0, 0),
+                   gdesc(true, S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho, 0), g_none);
+        } else {
+          gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
+          if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
+        }
+        for (int c = T; c < n; c += 64) {
+          double acc = dot_lds(Hux + c, ldh, Kl + np, ldh, mp, qv[c]);  // rows >= m are zero
+          if (rho != 0.0) acc -= rho * dot_lds(Kl + c, ldh, Kl + np, ldh, mp, 0.0);
+          sv[c] = acc;
         }
         wsync();
-        Walk w = start(by_n);
-        for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
-          const int i = w.q, j = w.r;
-          if (i > j) {
-            const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
-            S[i * lds + j] = v;
-            S[j * lds + i] = v;
+        if (coop) {
+          coop_run(kCoopSym, 1, gdesc(false, S, lds, S, lds, S, lds, n, n, n, 1.0, 0), g_none, g_none);  // S <- (S + S')/2
+        } else {
+          Walk w = start(by_n);
+          for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
+            const int i = w.q, j = w.r;
+            if (i > j) {
+              const double v = 0.5 * (S[i * lds + j] + S[j * lds + i]);
+              S[i * lds + j] = v;
+              S[j * lds + i] = v;
+            }
           }
         }
       }
@@ -1620,7 +1746,7 @@ struct Solver {
         const bool fail = backward(dV1, dV2);
         WSTAMP(t_bw += wstamp() - ts;)
         nbw++;
-        __syncthreads();  // phase end: gains written to global memory are read by other lanes in the rollout
+        block_sync();  // phase end: gains written to global memory are read by other lanes in the rollout
         if (!fail) break;
         if (rho >= o.bp_reg_max) { gave_up = true; break; }
         reg_update(true);
@@ -1809,7 +1935,7 @@ struct Solver {
     status = ALTRO_UNSOLVED;
     iters = 0;
     iters_outer = 0;
-    __syncthreads();  // the zeroed duals are read by other lanes
+    block_sync();  // the zeroed duals are read by other lanes
     double J = 0.0, cmax = 0.0;
     // one call site for ilqr(): the whole iLQR (rollouts, backward pass) is inlined into it
     const int nouter = has_con ? o.iterations_outer : 1;
@@ -1891,6 +2017,7 @@ struct Solver {
       P.n_iters[inst] += nit;
       P.n_ok[inst] += nok;
     }
+    coop_quit();  // releases the helper waves of a cooperative block: the ONLY exit of run(), reached on every path
   }
 };
 
@@ -1900,11 +2027,25 @@ struct Solver {
 #endif
 constexpr int wide_waves(int MC, bool SM) { return SM ? ALTRO_WIDE_WAVES_SM : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
 
+// threads per block: the n, m <= 16 instantiations are always one wave; the others may be launched as a cooperative
+// block of four (wide_block_threads)
 template <int MC, bool SM>
-__global__ void __launch_bounds__(64, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
+__global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
+  if (!SM && threadIdx.x >= 64) {  // helper waves: no solver state, only products on command
+    coop_helper(lds, lds_layout(P.n, P.m, P.Pn).cmd);
+    return;
+  }
   Solver<MC, SM> s(P, lds);
   s.run(mpc, first_step, nsteps);
+}
+
+// One wave per instance unless the LDS carve-up leaves room for a single instance per CU anyway (n >= 48 or so):
+// then three more waves on the CU's other SIMDs share the large products.
+inline int wide_block_threads(int n, int m, size_t lds_bytes) {
+  if (const char* e = getenv("ALTRO_WIDE_COOP"))  // diagnostic switch: 0 = never, 1 = every size with n or m > 16
+    return (atoi(e) != 0 && !(n <= 16 && m <= 16)) ? 256 : 64;
+  return (!(n <= 16 && m <= 16) && lds_bytes > 80 * 1024) ? 256 : 64;
 }
 
 // the separate shift_fill call of the fine-grained ABI

@@ -460,7 +460,7 @@ struct WideBackend {
     WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
     WCHK(hipEventRecord(h0, stream));
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(64), lds_bytes(), stream, params(), mpc, first_step, nsteps);
+    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes())), lds_bytes(), stream, params(), mpc, first_step, nsteps);
     WCHK(hipGetLastError());
     WCHK(hipEventRecord(h1, stream));
     WCHK(hipEventRecord(ev1, stream));
@@ -479,7 +479,7 @@ struct WideBackend {
     WCHK(hipSetDevice(device));
     int rc = prepare_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(64), lds_bytes(), stream, params(), 2, step, 1);
+    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes())), lds_bytes(), stream, params(), 2, step, 1);
     WCHK(hipGetLastError());
     kref = step + 1;
     return ALTRO_OK;
