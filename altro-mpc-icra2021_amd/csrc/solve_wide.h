@@ -167,12 +167,16 @@ __device__ __forceinline__ void gemm_strip(lds_d* C, int ldc, const lds_d* ap, i
 // one strip of 16 output rows: Cl, Al, Bl already point at this lane's element of the strip's first tile
 template <bool ACC>
 __device__ __forceinline__ void gemm_rows(lds_d* Cl, int ldc, const lds_d* Al, int lda, const lds_d* Bl, int ldb, int Nn, int K, double scale) {
+  // tiles of four share an A fragment; a single left-over tile rides with the last four (a lone tile is one
+  // dependent MFMA chain, ~250 cycles per k-step against 5 x 32 for a strip of five: W = S [A B] at m <= 16 is
+  // np/16 tiles of A and ONE of B)
   int j0 = 0;
-  for (; j0 + 64 <= Nn; j0 += 64) gemm_strip<ACC, 4>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
-  const int rem = (Nn - j0) >> 4;
-  if (rem == 3) gemm_strip<ACC, 3>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
-  else if (rem == 2) gemm_strip<ACC, 2>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
-  else if (rem == 1) gemm_strip<ACC, 1>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  int t = Nn >> 4;
+  for (; t >= 6 || t == 4; t -= 4, j0 += 64) gemm_strip<ACC, 4>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  if (t == 5) gemm_strip<ACC, 5>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  else if (t == 3) gemm_strip<ACC, 3>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  else if (t == 2) gemm_strip<ACC, 2>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
+  else if (t == 1) gemm_strip<ACC, 1>(Cl + j0, ldc, Al, lda, Bl + j0, ldb, K, scale);
 }
 
 template <bool ACC>
@@ -192,7 +196,7 @@ __device__ __forceinline__ void gemm_tn(double* C, int ldc, const double* AT, in
 // barrier for a command in LDS -- a list of products, or the symmetrisation of S -- take their share of the 16-row
 // strips, and wait again.  Every command is two s_barrier for all four waves; wave 0 sends QUIT when it is done.
 struct GemmDesc {
-  int C, ldc, A, lda, B, ldb, M, Nn, K, acc, rot, pad;  // operands as offsets (doubles) from the LDS base
+  int C, ldc, A, lda, B, ldb, M, Nn, K, acc, w0, wn;  // operands as offsets (doubles) from the LDS base; strip st runs on wave w0 + st % wn
   double scale;
 };
 struct CoopCmd {
@@ -210,7 +214,7 @@ __device__ __forceinline__ void coop_exec(double* lds, const CoopCmd* c, int wv,
       const lds_d* Al = (const lds_d*)lds + d.A + q * d.lda + r16;
       const lds_d* Bl = (const lds_d*)lds + d.B + q * d.ldb + r16;
       for (int st = 0; 16 * st < d.M; ++st) {
-        if (((st + d.rot) & (nw - 1)) != wv) continue;  // strips of descriptors that accumulate into the same C keep their wave
+        if (((d.w0 + st % d.wn) & (nw - 1)) != wv) continue;  // descriptors that accumulate into the same C give a strip the same wave
         if (d.acc) gemm_rows<true>(Cl + 16 * st * d.ldc, d.ldc, Al + 16 * st, d.lda, Bl, d.ldb, d.Nn, d.K, d.scale);
         else gemm_rows<false>(Cl + 16 * st * d.ldc, d.ldc, Al + 16 * st, d.lda, Bl, d.ldb, d.Nn, d.K, d.scale);
       }
@@ -352,12 +356,12 @@ struct Solver {
   // cooperative block (four waves, see coop_exec): wave 0 posts a command for the helper waves and takes its share
   __device__ __forceinline__ bool coop_on() const { return !SM && blockDim.x > 64; }
   __device__ __forceinline__ GemmDesc gdesc(bool acc, const double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int Nn,
-                                            int K, double scale, int rot) const {
+                                            int K, double scale, int w0, int wn) const {
     GemmDesc d;
     d.C = (int)(C - lds_base); d.ldc = ldc;
     d.A = (int)(A - lds_base); d.lda = lda;
     d.B = (int)(B - lds_base); d.ldb = ldb;
-    d.M = M; d.Nn = Nn; d.K = K; d.acc = acc ? 1 : 0; d.rot = rot; d.pad = 0; d.scale = scale;
+    d.M = M; d.Nn = Nn; d.K = K; d.acc = acc ? 1 : 0; d.w0 = w0; d.wn = wn; d.scale = scale;
     return d;
   }
   __device__ __forceinline__ void coop_run(int op, int ng, const GemmDesc& g0, const GemmDesc& g1, const GemmDesc& g2) {
@@ -1572,10 +1576,12 @@ struct Solver {
         const bool coop = coop_on();
         const GemmDesc g_none = {};
         if (coop) {
-          coop_run(kCoopGemm, 1, gdesc(false, W, ldg, S, lds, G, ldg, np, nzp, np, 1.0, 0), g_none, g_none);  // W = S [A B]
-          coop_run(kCoopGemm, 3, gdesc(false, Hux, ldh, G + np, ldg, W, ldg, mp, np, np, 1.0, 0),           // Qux = B' S A
-                   gdesc(false, Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np, 1.0, 1),                    // Quu = B' S B
-                   gdesc(false, S, lds, G, ldg, W, ldg, np, np, np, 1.0, 2));                               // Qxx = A' S A
+          // the strips of Qux and Quu (one each at m <= 16, and Quu a lone tile) on waves 0 and 1, those of Qxx on 2 and 3
+          const int wq = mp > 16 ? 4 : 1;
+          coop_run(kCoopGemm, 1, gdesc(false, W, ldg, S, lds, G, ldg, np, nzp, np, 1.0, 0, 4), g_none, g_none);  // W = S [A B]
+          coop_run(kCoopGemm, 3, gdesc(false, Hux, ldh, G + np, ldg, W, ldg, mp, np, np, 1.0, 0, wq),          // Qux = B' S A
+                   gdesc(false, Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np, 1.0, 1, wq),                   // Quu = B' S B
+                   gdesc(false, S, lds, G, ldg, W, ldg, np, np, np, 1.0, mp > 16 ? 0 : 2, mp > 16 ? 4 : 2));   // Qxx = A' S A
         } else {
           gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
           wsync();
@@ -1592,8 +1598,8 @@ struct Solver {
         wsync();
         if (Pn > 0) {
           if (coop) {
-            coop_run(kCoopGemm, 3, gdesc(true, Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp, 1.0, 0),
-                     gdesc(true, Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp, 1.0, 1), gdesc(true, S, lds, DA, ldg, Ac, ldg, np, np, Pp, 1.0, 2));
+            coop_run(kCoopGemm, 3, gdesc(true, Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp, 1.0, 0, 1),
+                     gdesc(true, Huu, ldu, DA + np, ldg, Ac + np, ldg, mp, mp, Pp, 1.0, 1, 1), gdesc(true, S, lds, DA, ldg, Ac, ldg, np, np, Pp, 1.0, 0, 4));
           } else {
             gemm_tn<true>(S, lds, DA, ldg, Ac, ldg, np, np, Pp);
             gemm_tn<true>(Hux, ldh, DA + np, ldg, Ac, ldg, mp, np, Pp);
@@ -1661,8 +1667,8 @@ struct Solver {
         }
         // S = Qxx + Qux'K - rho K'K ; s = Qx + Qux'd - rho K'd
         if (coop) {
-          coop_run(kCoopGemm, rho != 0.0 ? 2 : 1, gdesc(true, S, lds, Hux, ldh, Kl, ldh, np, np, mp, 1.0, 0),
-                   gdesc(true, S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho, 0), g_none);
+          coop_run(kCoopGemm, rho != 0.0 ? 2 : 1, gdesc(true, S, lds, Hux, ldh, Kl, ldh, np, np, mp, 1.0, 0, 4),
+                   gdesc(true, S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho, 0, 4), g_none);
         } else {
           gemm_tn<true>(S, lds, Hux, ldh, Kl, ldh, np, np, mp);
           if (rho != 0.0) gemm_tn<true>(S, lds, Kl, ldh, Kl, ldh, np, np, mp, -rho);
@@ -1674,7 +1680,7 @@ struct Solver {
         }
         wsync();
         if (coop) {
-          coop_run(kCoopSym, 1, gdesc(false, S, lds, S, lds, S, lds, n, n, n, 1.0, 0), g_none, g_none);  // S <- (S + S')/2
+          coop_run(kCoopSym, 1, gdesc(false, S, lds, S, lds, S, lds, n, n, n, 1.0, 0, 4), g_none, g_none);  // S <- (S + S')/2
         } else {
           Walk w = start(by_n);
           for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2
