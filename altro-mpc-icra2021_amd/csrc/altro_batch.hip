@@ -1241,8 +1241,10 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
 int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed) {
   return guard(h, [&]() -> int32_t {
     if (!h || !confirmed) return ALTRO_ERR_INVALID_ARG;
-    if (h->wide) {  // the one-wave-per-instance kernel runs every iteration in full
-      for (int32_t b = 0; b < h->d.batch; ++b) confirmed[b] = 0;
+    if (h->wide) {
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipStreamSynchronize(h->wide->stream));
+      HIPCHK(h, hipMemcpy(confirmed, h->wide->n_gconf, (size_t)h->d.batch * sizeof(long long), hipMemcpyDeviceToHost));
       return ALTRO_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));

@@ -27,6 +27,11 @@ namespace altro_wide {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxN = 64, kMaxM = 32, kMaxP = 64;
+// packed size of the factor the costate sweep reads back, for the control-size class of m (m <= 16)
+__host__ __device__ inline int wide_fac_size(int m) {
+  const int mc = m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : 16;
+  return mc * (mc + 1) / 2;
+}
 
 struct Params {
   int B, n, m, N, Nt, np, mp, Pn, Pp;
@@ -50,7 +55,10 @@ struct Params {
   double* trash;        // [B][64] sink for the stores of lanes that hold no element (keeps loop bodies branch-free)
   int *iters, *iters_outer, *status;
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
-  long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok;
+  long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf;
+  double* Qz;           // [B][N][n+m] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced (costate sweep)
+  double* fac;          // [B][N][MC (MC + 1) / 2] (n, m <= 16) L D L' factor of Quu_k of the last backward pass: strictly lower
+                        // triangle of L and 1 / D on the diagonal, row-major packed (costate sweep)
   const double *noise, *noise_w;
   const int* noise_grp;
   int noise_mode, mpc_shift;
@@ -313,6 +321,11 @@ struct Solver {
   double mu, rho, drho;
   int dj_zero, status, iters, iters_outer;
   bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
+  // costate sweep (adjoint_row): per-lane active-set hashes of the last backward pass and of the trajectory whose
+  // gradient is in Qz; bw_plain: that pass ran without regularisation; qvalid: Qz describes plane cur
+  unsigned bw_hash = 0u, q_hash = 0u;
+  bool bw_plain = false, qvalid = false;
+  long long ngc = 0;
   long long nbw, nro, ntr;
   long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_du = 0, t_sh = 0, t_run = 0, t_td = 0;
   // per-lane constants (lane T as state element T and as control element T), loaded once
@@ -548,6 +561,7 @@ struct Solver {
     bool limit;
     bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
     bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
+    unsigned qh;     // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
   };
 
   // ---- second-order cone rows (oracle soc_project / con_cost / cost_expansion) -------------
@@ -866,6 +880,7 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = CLOSED && !wave_any(chg);
     r.tiny = CLOSED && !wave_any(big);
+    r.qh = 0u;
     return r;
   }
 
@@ -902,7 +917,7 @@ struct Solver {
     double v[4];
   };
 
-  template <bool CLOSED, bool LTV>
+  template <bool CLOSED, bool LTV, bool ROWS>
   __device__ __forceinline__ RollOut rollout_row(double alpha) {
     // The lane index is made opaque here: everything lane-dependent below (a few dozen addresses) is then computed
     // inside this function.  Otherwise LLVM hoists it, with the lane-dependent invariants of every other phase, to
@@ -914,7 +929,7 @@ struct Solver {
     const double* Us = Up(cur);
     double* Xd = CLOSED ? Xp(cur ^ 1) : Xp(cur);
     double* Ud = CLOSED ? Up(cur ^ 1) : Up(cur);
-    const bool isx = t < n, isu = t < m, isr = t < Pn, rows = Pn > 0;
+    const bool isx = t < n, isu = t < m, isr = ROWS && t < Pn, rows = ROWS;
     const unsigned Tn = isx ? t : n - 1, Tm = isu ? t : m - 1, Tr = isr ? t : 0;
     double* gtrash = P.trash + (size_t)inst * 64;  // [64]: lane t's sink is word t
     // per-knot operands of the generic rows; a problem without rows reads (and ignores) the trash line instead
@@ -925,13 +940,21 @@ struct Solver {
     const int ldg_ = ly.ldg;
     const unsigned nn = n * n, nm = n * m;
     lds_d* const ltrash = (lds_d*)zb + nzp;  // LDS sink (qz[0], dead during rollouts)
-    double ac[32], ab[32];  // row t of the constraint table; row t of [A B] (time-invariant: loaded once)
+    // Row t of the constraint table (ac), of [A B] (ab), and -- closed loop, for the gradient A_c' g left in Qz --
+    // columns t and 16 + t of the table (acx, acu) are read from LDS at every knot rather than held across the loop:
+    // 190 registers held for the whole rollout pushed the loop into scratch (each reload a vmcnt(0)).  Rows beyond
+    // Pn of Ac are zero or never count (on = false), the table's pad columns are zero.
+    const lds_d* acrow = (const lds_d*)Ac + (rows ? Tr * ldg_ : 0);
+    const lds_d* accol = (const lds_d*)Ac;
+    const lds_d* abrow = (const lds_d*)G + Tn * ldg_;
+    const int lastrow = Pn > 0 ? Pn - 1 : 0;
+    double ab[32];  // row t of [A B]: time-invariant dynamics keep it for the whole rollout, per-knot ones refill it
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const double a = Ac[Tr * ldg_ + c], g = G[Tn * ldg_ + c];
-      ac[c] = (rows & isr) ? a : 0.0;
-      ab[c] = g;
-    }
+    for (int c = 0; c < 32; ++c) ab[c] = abrow[c];
+    // Qz is written by the alpha = 1 trial only (a smaller step leaves the plane describing that trial: qvalid = false)
+    const bool wq = CLOSED && alpha == 1.0;
+    double* Qzi = P.Qz + (size_t)inst * N * nz;
+    unsigned qh = 0u;
     double fT = LTV ? 0.0 : fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
@@ -1019,6 +1042,19 @@ struct Solver {
     for (int k = 0; k < N - 1; ++k) {
       const Ld d3 = ld(k + 3);
       kq1 = k_request(k + 2);
+      double ac[32], acx[16], acu[16];
+      if constexpr (ROWS) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ac[c] = acrow[c];
+        if constexpr (CLOSED) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = r < Pn ? r : lastrow;  // rows beyond Pn: g_r = 0
+            acx[r] = accol[rr * ldg_ + Tn];
+            acu[r] = accol[rr * ldg_ + 16 + Tm];
+          }
+        }
+      }
       double kp[16];
       if constexpr (CLOSED) {
         const lds_d* st = kpark[k & 1];
@@ -1051,16 +1087,35 @@ struct Solver {
       }
       J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
       J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
-      {  // generic rows: value, AL cost, violation
-        double v = RowDot<16>::run(ac, xb, d.bc);
+      // generic rows: value, AL cost, violation
+      double v = 0.0;
+      if constexpr (ROWS) {
+        v = RowDot<16>::run(ac, xb, d.bc);
         v = RowDot<16>::run(ac + 16, uv, v);
-        const bool on = isr & (d.ct != 0), eq = d.ct == 1;
-        const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+      }
+      const bool on = isr & (d.ct != 0), eq = d.ct == 1;
+      const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+      {
         const double cj = d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
         J += on ? cj : 0.0;
         viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
       }
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
+      if (CLOSED) {  // gradient of the AL cost at this knot and the active-set code, for the costate sweep
+        const double g = on ? d.lam + (act ? mu * v : 0.0) : 0.0;
+        double qx = cwx * (xb - d.xr), qu = cwu * (uv - d.ur);
+        box_grad(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx, qx);
+        box_grad(uv, cumax, cumin, d.luh, d.lul, isu & bx, qu);
+        if constexpr (ROWS) {
+          qx = RowDot<16>::run(acx, g, qx);
+          qu = RowDot<16>::run(acu, g, qu);
+        }
+        const unsigned code = box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2) |
+                              ((on & act) ? 16u : 0u);
+        qh = hash_add(qh, code, k);
+        *((wq & isx) ? Qzi + (unsigned)k * nz + t : gtrash + t) = qx;
+        *((wq & isu) ? Qzi + (unsigned)k * nz + n + t : gtrash + t) = qu;
+      }
       double xn = RowDot<16>::run(ab, xb, fT);
       xn = RowDot<16>::run(ab + 16, uv, xn);
       k_park(kq0, kpark[(k & 1) ^ 1]);  // block k + 1
@@ -1076,11 +1131,18 @@ struct Solver {
       d2 = d3;
     }
     *(isx ? Xd + (unsigned)(N - 1) * n + t : gtrash + t) = xb;
+    double ac[16], acx[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      ac[c] = ROWS ? (double)acrow[c] : 0.0;
+      acx[c] = ROWS ? (double)accol[(c < Pn ? c : lastrow) * ldg_ + Tn] : 0.0;
+    }
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
-    {  // rows of the terminal knot see the state only
-      const double v = RowDot<16>::run(ac, xb, d.bc);
-      const bool on = isr & (d.ct != 0), eq = d.ct == 1;
-      const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+    // rows of the terminal knot see the state only
+    const double v = ROWS ? RowDot<16>::run(ac, xb, d.bc) : 0.0;
+    const bool on = isr & (d.ct != 0), eq = d.ct == 1;
+    const bool act = eq | (v >= 0.0) | (d.lam > 0.0);
+    {
       const double cj = d.lam * v + (act ? 0.5 * mu * v * v : 0.0);
       J += on ? cj : 0.0;
       viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
@@ -1089,6 +1151,13 @@ struct Solver {
     if (CLOSED) {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
+      const bool bxT = box_at(N - 1);
+      const double g = on ? d.lam + (act ? mu * v : 0.0) : 0.0;
+      double qx = cwfx * (xb - d.xr);
+      box_grad(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT, qx);
+      qx = RowDot<16>::run(acx, g, qx);
+      qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT) | ((on & act) ? 16u : 0u), N - 1);
+      *((wq & isx) ? Qzi + (unsigned)(N - 1) * nz + t : gtrash + t) = qx;
     }
     block_sync();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
@@ -1097,7 +1166,171 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = CLOSED && !wave_any(chg);
     r.tiny = CLOSED && !wave_any(big);
+    r.qh = qh;
     return r;
+  }
+
+  // Costate sweep (default mode; the problems of the row rollouts): lambda_N = l_x(N), lambda_k = l_x(k) + A_k' lambda_{k+1},
+  // g_k = l_u(k) + B_k' lambda_{k+1}, d_k = -Quu_k^-1 g_k -- the first-order part of the backward pass, ~400
+  // instructions per knot instead of ~3000.  l_x, l_u at the current trajectory (tracking cost, box terms, A_c' g of
+  // the generic rows) were left in Qz by the alpha = 1 rollout that produced it; Quu_k = L D L' is the factor the last
+  // backward pass stored (same active set = same Quu).  Inside a fixed active set the problem is quadratic, and by
+  // induction over the knots every feedforward term of a new backward pass vanishes iff every d_k of this recursion
+  // does.  Returns true if |d_k,a| <= 1e-9 (1 + |u_k,a|) at every knot -- the test of the confirmation iterations.
+  // Lane T holds lambda_T, g_T; column T of A_k and of B_k in registers (time-invariant: loaded once; per-knot
+  // dynamics: from the blocks parked in LDS, requested two knots ahead as in the rollouts); the factor of knot k is
+  // parked in LDS a knot ahead and every lane solves for the whole d_k.
+  template <bool LTV>
+  __device__ __forceinline__ bool adjoint_row() {
+    constexpr int MP = MC > 0 ? MC : 4, FS = MP * (MP + 1) / 2;
+    int t = T;
+    asm volatile("" : "+v"(t));
+    const bool isx = t < n, isu = t < m;
+    const unsigned Tn = isx ? t : n - 1, Tm = isu ? t : m - 1;
+    const int ldg_ = ly.ldg;
+    const unsigned nn = n * n, nm = n * m;
+    lds_d* const ltrash = (lds_d*)zb + nzp;
+    const double* Qzi = P.Qz + (size_t)inst * N * nz;
+    const double* faci = P.fac + (size_t)inst * N * FS;
+    const double* Us = Up(cur);
+    double ca[16], cb[16];  // column t of A, column t of B
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ca[i] = G[i * ldg_ + Tn];
+      cb[i] = G[i * ldg_ + 16 + Tm];
+    }
+    auto dyn_req = [&](int kk) __attribute__((always_inline)) {
+      const int k = kk > 0 ? kk : 0;
+      const double *A_ = Ak(k), *B_ = Bk(k);
+      DynRegs q;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        q.a[u] = ldg(A_, e < nn ? e : nn - 1);
+        q.b[u] = ldg(B_, e < nm ? e : nm - 1);
+      }
+      q.f = 0.0;
+      return q;
+    };
+    auto dyn_park = [&](const DynRegs& q, lds_d* st) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned e = t + 64 * u;
+        *(e < nn ? st + e : ltrash) = q.a[u];
+        *(e < nm ? st + nn + e : ltrash) = q.b[u];
+      }
+    };
+    struct Fk {
+      double v[3];  // FS <= 136 elements over 64 lanes
+    };
+    auto fac_req = [&](int kk) __attribute__((always_inline)) {
+      const unsigned k = kk > 0 ? kk : 0;
+      Fk f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const unsigned e = t + 64 * u;
+        f.v[u] = ldg(faci, k * FS + (e < FS ? e : FS - 1));
+      }
+      return f;
+    };
+    auto fac_park = [&](const Fk& f, lds_d* st) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const unsigned e = t + 64 * u;
+        *(e < FS ? st + e : ltrash) = f.v[u];
+      }
+    };
+    struct Qk {
+      double qx, qu, us;
+    };
+    auto ldq = [&](int kk) __attribute__((always_inline)) {
+      const unsigned k = kk > 0 ? kk : 0;
+      Qk q;
+      q.qx = ldg(Qzi, k * nz + Tn);
+      q.qu = ldg(Qzi, k * nz + n + Tm);
+      q.us = ldg(Us, k * m + Tm);
+      return q;
+    };
+    lds_d* const park[2] = {(lds_d*)W, (lds_d*)Hux};
+    lds_d* const fpark[2] = {(lds_d*)S, (lds_d*)S + 136};
+    DynRegs dq[2] = {};
+    Fk fq[2];
+    Qk qs[4];
+    const int kt = N - 2;  // first knot of the sweep
+    if (LTV) {
+      dq[0] = dyn_req(kt);
+      dyn_park(dq[0], park[kt & 1]);
+      dq[1] = dyn_req(kt - 1);
+    }
+    fq[0] = fac_req(kt);
+    fac_park(fq[0], fpark[kt & 1]);
+    fq[1] = fac_req(kt - 1);
+    qs[0] = ldq(kt);
+    qs[1] = ldq(kt - 1);
+    qs[2] = ldq(kt - 2);
+    double lam = isx ? ldg(Qzi, (unsigned)(N - 1) * nz + Tn) : 0.0;
+    bool dbig = false;
+    wsync();
+    auto knot = [&](auto uc, int k) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc)::value;  // position in the group of four: register slots are compile-time
+      const bool live = k >= 0;
+      qs[(U + 3) & 3] = ldq(k - 3);
+      fq[U & 1] = fac_req(k - 2);  // block k is in LDS, block k - 1 waits in slot (U + 1) & 1
+      if constexpr (LTV) {
+        const lds_d* st = park[k & 1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          ca[i] = st[(i < n ? i : n - 1) + n * Tn];
+          cb[i] = st[nn + (i < n ? i : n - 1) + n * Tm];
+        }
+        dq[U & 1] = dyn_req(k - 2);
+      }
+      const double gx = RowDot<16>::run(ca, lam, qs[U].qx);
+      double gu = RowDot<16>::run(cb, lam, qs[U].qu);
+      gu = isu ? gu : 0.0;
+      // d_k = Quu_k^-1 g_k (the sign does not matter here), every lane for the whole vector
+      double y[MP];
+      gather_row<MP>(y, gu);
+      const lds_d* fk = fpark[k & 1];
+#pragma unroll
+      for (int j = 0; j < MP; ++j)          // forward: L y = g
+#pragma unroll
+        for (int i = j + 1; i < MP; ++i) y[i] -= fk[i * (i + 1) / 2 + j] * y[j];
+#pragma unroll
+      for (int r = 0; r < MP; ++r) y[r] *= fk[r * (r + 1) / 2 + r];  // 1 / D
+#pragma unroll
+      for (int j = MP - 1; j >= 0; --j)     // backward: L' d = y
+#pragma unroll
+        for (int i = 0; i < j; ++i) y[i] -= fk[j * (j + 1) / 2 + i] * y[j];
+      double dsel = 0.0;
+#pragma unroll
+      for (int r = 0; r < MP; ++r) dsel = (t == r) ? y[r] : dsel;
+      dbig = dbig | (live & isu & !(fabs(dsel) <= 1e-9 * (1.0 + fabs(qs[U].us))));
+      lam = (live & isx) ? gx : lam;
+      fac_park(fq[(U + 1) & 1], fpark[(k - 1) & 1]);
+      if constexpr (LTV) dyn_park(dq[(U + 1) & 1], park[(k - 1) & 1]);
+      wsync();
+    };
+    for (int k = kt; k >= 0; k -= 4) {
+      knot(std::integral_constant<int, 0>{}, k);
+      knot(std::integral_constant<int, 1>{}, k - 1);
+      knot(std::integral_constant<int, 2>{}, k - 2);
+      knot(std::integral_constant<int, 3>{}, k - 3);
+    }
+    return !wave_any(dbig);
+  }
+
+  // y[a] = element a of the row vector v (lanes a of this 16-lane row), a < MP
+  template <int MP>
+  static __device__ __forceinline__ void gather_row(double (&y)[MP], double v) {
+    gather_row_at<MP, 0>(y, v);
+  }
+  template <int MP, int A>
+  static __device__ __forceinline__ void gather_row_at(double (&y)[MP], double v) {
+    if constexpr (A < MP) {
+      y[A] = row_bcast<A>(v);
+      gather_row_at<MP, A + 1>(y, v);
+    }
   }
 
   __device__ __forceinline__ bool row_rollouts() const {
@@ -1108,8 +1341,12 @@ struct Solver {
     phase_begin();
     if constexpr (SM) {
       if (row_rollouts()) {
-        if (P.ltv) return open ? rollout_row<false, true>(0.0) : rollout_row<true, true>(alpha);
-        return open ? rollout_row<false, false>(0.0) : rollout_row<true, false>(alpha);
+        if (Pn > 0) {
+          if (P.ltv) return open ? rollout_row<false, true, true>(0.0) : rollout_row<true, true, true>(alpha);
+          return open ? rollout_row<false, false, true>(0.0) : rollout_row<true, false, true>(alpha);
+        }
+        if (P.ltv) return open ? rollout_row<false, true, false>(0.0) : rollout_row<true, true, false>(alpha);
+        return open ? rollout_row<false, false, false>(0.0) : rollout_row<true, false, false>(alpha);
       }
     } else {
       if (Pn == 0 && !P.ltv) return open ? rollout_simple<false>(0.0) : rollout_simple<true>(alpha);
@@ -1191,6 +1428,7 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = !open && !wave_any(chg);
     r.tiny = !open && !wave_any(big);
+    r.qh = 0u;
     return r;
   }
 
@@ -1218,10 +1456,33 @@ struct Solver {
     }
   }
 
+  // Active-set hash of one lane: a position-weighted sum of the per-knot codes, so that the backward pass (knots in
+  // descending order) and a rollout (ascending) arrive at the same number for the same active set.  Code of lane T at
+  // a knot: bits 0-1 the box sides of x_T that enter the Hessian, bits 2-3 those of u_T, bit 4 generic row T active.
+  static __device__ __forceinline__ unsigned hash_add(unsigned h, unsigned code, int k) {
+    const unsigned mk = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;
+    return __umul24(code, mk) + h;
+  }
+  static __device__ __forceinline__ unsigned box_code(double z, double zmx, double zmn, double lhi, double llo, bool on) {
+    const bool bh = on & (zmx < 1e300), bl = on & (zmn > -1e300);
+    const bool ah = ((z - zmx) >= 0.0) | (lhi > 0.0), al = ((zmn - z) >= 0.0) | (llo > 0.0);
+    return ((bh & ah) ? 1u : 0u) | ((bl & al) ? 2u : 0u);
+  }
+
+  // gradient of the box terms of one element (what box_expand adds to q), branch-free
+  __device__ __forceinline__ void box_grad(double z, double zmx, double zmn, double lhi, double llo, bool on, double& q) const {
+    const double chi = z - zmx, clo = zmn - z;
+    const bool bh = on & (zmx < 1e300), bl = on & (zmn > -1e300);
+    const bool ah = (chi >= 0.0) | (lhi > 0.0), al = (clo >= 0.0) | (llo > 0.0);
+    q += bh ? lhi + (ah ? mu * chi : 0.0) : 0.0;
+    q -= bl ? llo + (al ? mu * clo : 0.0) : 0.0;
+  }
+
   // cost_expansion! at knot k of plane cur: gradient qz, Hessian diagonal hz (padded z layout), and
   // for the generic rows the tables Ac, DA = diag(I_mu) Ac with A'g already added to qz
-  __device__ __forceinline__ void expansion(int k, bool term, const KnotLd& d) {
+  __device__ __forceinline__ void expansion(int k, bool term, const KnotLd& d, unsigned& code) {
     const bool bx = box_at(k);
+    code = box_code(d.xs, cxmax, cxmin, d.lxh, d.lxl, bx & (T < n)) | (box_code(d.us, cumax, cumin, d.luh, d.lul, bx & (T < m) & !term) << 2);
     if (T < n) {
       const double x = d.xs;
       zb[T] = x;
@@ -1259,6 +1520,7 @@ struct Solver {
               const bool act = (ct == 1) || (v >= 0.0) || (lam > 0.0);
               g = lam + (act ? mu * v : 0.0);
               D = act ? mu : 0.0;
+              code |= act ? 16u : 0u;
             }
           }
         }
@@ -1359,7 +1621,7 @@ struct Solver {
     return __builtin_fma(y, e, y);
   }
   template <int MP>
-  __device__ __forceinline__ bool factor_solve_lane() {
+  __device__ __forceinline__ bool factor_solve_lane(double* facout) {
     const int ldh = ly.ldh, ldu = ly.ldu;
     const lds_d* Hl = (const lds_d*)Huu;
     double a[MP][MP], inv[MP];
@@ -1385,6 +1647,14 @@ struct Solver {
       for (int c = j + 1; c < MP; ++c) a[c][j] = f[c];
     }
     if (fail) return true;  // wave-uniform: every lane saw the same pivots
+    if (SM && T == 0) {  // the factor of this knot, for the costate sweep (78 doubles at MP = 12, one lane)
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) facout[i * (i + 1) / 2 + j] = a[i][j];
+        facout[i * (i + 1) / 2 + i] = inv[i];
+      }
+    }
     for (int c0 = 0; c0 <= np; c0 += 64) {
       const int c = c0 + T;
       const bool mine = (c < n) || (c == np);
@@ -1416,7 +1686,9 @@ struct Solver {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
-    expansion(N - 1, true, load_knot(N - 1, true, 2, Xp(cur), Up(cur)));
+    unsigned hash = 0u, kcode = 0u;
+    expansion(N - 1, true, load_knot(N - 1, true, 2, Xp(cur), Up(cur)), kcode);
+    hash = hash_add(hash, kcode, N - 1);
     if (T < n) {
       S[T * lds + T] = hz[T];
       sv[T] = qz[T];
@@ -1440,7 +1712,8 @@ struct Solver {
       DynRegs dq = {};
       if (ahead) dq = dyn_request(k > 0 ? k - 1 : 0);
       else if (P.ltv) load_dyn(k);
-      expansion(k, false, kd);  // ends with a barrier
+      expansion(k, false, kd, kcode);  // ends with a barrier
+      hash = hash_add(hash, kcode, k);
       const double us_k = kd.us;
       kd = kdn;
       WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
@@ -1512,7 +1785,7 @@ struct Solver {
         }
         wsync();
         WSTAMP(const long long b2 = wstamp(); t_b += b2 - b1;)
-        if (factor_solve_lane<MC>()) return true;
+        if (factor_solve_lane<MC>(P.fac + ((size_t)inst * N + k) * (MC * (MC + 1) / 2))) return true;
         wsync();
         WSTAMP(b3 = wstamp(); t_c += b3 - b2;)
         {  // dV = (d'Qu, 1/2 d'Quu d) with Quu d = -Qu - rho d
@@ -1614,7 +1887,7 @@ struct Solver {
         if (MC > 0 && T >= m && T < mp) Huu[T * ldu + T] = 1.0;  // factor_solve_lane: identity in the pad rows
         wsync();
         if constexpr (MC > 0) {
-          if (factor_solve_lane<MC>()) return true;
+          if (factor_solve_lane<MC>(nullptr)) return true;
         } else {
           // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
           for (int j = 0; j < m; ++j) {
@@ -1701,6 +1974,7 @@ struct Solver {
       WSTAMP(t_d += wstamp() - b3;)
     }
     dtiny = !wave_any(dbig);
+    bw_hash = hash;
     return false;
   }
 
@@ -1744,31 +2018,64 @@ struct Solver {
     }
     double J_prev = r0.J, J = r0.J;
     cmax = r0.cmax;
+    qvalid = false;  // the duals / the penalty may have changed since Qz was written
+    bw_plain = false;
     for (int it = 0; it < o.iterations_inner; ++it) {
-      double dV1, dV2;
+      double dV1 = 0.0, dV2 = 0.0;
       bool gave_up = false;
-      while (true) {  // regularisation restarts
+      // Confirmation by the costate sweep (default mode; altro_opts.strict = 1 never takes it): from the second
+      // iteration of an inner solve on, if the last backward pass ran without regularisation, the trajectory came out of an
+      // alpha = 1 rollout (its gradient is in Qz) and crossed no active-set boundary on the way, the first-order sweep
+      // decides whether a backward pass here would return feedforward terms at rounding level.  If so the
+      // iteration is booked as converged without that pass; the gains in memory are its K, the feedforward terms
+      // are set to zero.
+      bool gconf = false;
+      if constexpr (SM) {
+        const bool tryg = !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && row_rollouts() && !wave_any(q_hash != bw_hash) &&
+                          (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
+#ifdef ALTRO_DEBUG_SWEEP
+        if (!o.strict && it >= 1) ntr += 1000000 * ((bw_plain ? 1 : 0) + (qvalid ? 10 : 0) + (rho == 0.0 ? 100 : 0) + (!wave_any(q_hash != bw_hash) ? 1000 : 0));
+#endif
+        if (tryg) {
+          phase_begin();
+          WSTAMP(const long long ts = wstamp();)
+          gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
+          WSTAMP(t_td += wstamp() - ts;)
+          if (gconf) {
+            ngc++;
+            for (int k = 0; k < N - 1; ++k)
+              if (T < m) dgi[(size_t)k * m + T] = 0.0;
+            block_sync();
+          }
+        }
+      }
+      while (!gconf) {  // regularisation restarts
+        const bool plain = rho == 0.0;
         WSTAMP(const long long ts = wstamp();)
         const bool fail = backward(dV1, dV2);
         WSTAMP(t_bw += wstamp() - ts;)
         nbw++;
         block_sync();  // phase end: gains written to global memory are read by other lanes in the rollout
-        if (!fail) break;
+        if (!fail) {
+          bw_plain = plain;
+          break;
+        }
         if (rho >= o.bp_reg_max) { gave_up = true; break; }
         reg_update(true);
       }
       if (gave_up) { status = ALTRO_NO_PROGRESS; break; }
-      reg_update(false);
+      if (!gconf) reg_update(false);
       // forwardpass!
       double alpha = 1.0, z = -1.0, cm = 0.0;
       J = __builtin_inf();
       int ls = 0;
       bool accepted = true;
+      unsigned qh1 = 0u;
       // Default-mode shortcuts, the ones of solve_dpp16.h (altro_opts.strict = 1 takes none of them).  Confirmation
       // iteration: every feedforward term of the backward pass is at rounding level, so the rollout, its line search
       // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
       // the outcome -- the iteration is booked as converged on the trajectory it holds.
-      const bool confirm = !o.strict && dtiny && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
+      const bool confirm = gconf || (!o.strict && dtiny && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev))));
       if (confirm) {
         J = J_prev;
         cm = cmax;
@@ -1787,7 +2094,12 @@ struct Solver {
         WSTAMP(const long long ts = wstamp();)
         const RollOut r = rollout(false, alpha);
         WSTAMP(t_ro += wstamp() - ts;)
-        if (ls == 0) nro++; else ntr++;
+        if (ls == 0) {
+          nro++;
+          qh1 = r.qh;
+        } else {
+          ntr++;
+        }
         if (r.limit) { ls++; alpha *= 0.5; continue; }
         J = r.J;
         cm = r.cmax;
@@ -1802,6 +2114,10 @@ struct Solver {
       }
       if (accepted) alpha *= 2.0;
       if (confirm) alpha = 1.0;
+      if (!confirm) {  // Qz describes the new plane only if the alpha = 1 trial was the one accepted
+        qvalid = accepted && alpha == 1.0;
+        q_hash = qh1;
+      }
       if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
       if (accepted) cur ^= 1;  // copy_trajectories!
       cmax = cm;
@@ -2022,6 +2338,7 @@ struct Solver {
       P.n_solves[inst] += nsolve;
       P.n_iters[inst] += nit;
       P.n_ok[inst] += nok;
+      P.n_gconf[inst] += ngc;
     }
     coop_quit();  // releases the helper waves of a cooperative block: the ONLY exit of run(), reached on every path
   }
