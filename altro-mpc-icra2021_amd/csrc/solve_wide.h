@@ -56,7 +56,7 @@ struct Params {
   int *iters, *iters_outer, *status;
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
   long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf;
-  double* Qz;           // [B][N][n+m] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced (costate sweep)
+  double* Qz;           // [B][N][n+m] scratch of the costate sweep: gradient of the AL cost at every knot of plane cur
   double* fac;          // [B][N][MC (MC + 1) / 2] (n, m <= 16) L D L' factor of Quu_k of the last backward pass: strictly lower
                         // triangle of L and 1 / D on the diagonal, row-major packed (costate sweep)
   const double *noise, *noise_w;
@@ -322,7 +322,7 @@ struct Solver {
   int dj_zero, status, iters, iters_outer;
   bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
   // costate sweep (adjoint_row): per-lane active-set hashes of the last backward pass and of the trajectory whose
-  // gradient is in Qz; bw_plain: that pass ran without regularisation; qvalid: Qz describes plane cur
+  // plane cur holds; bw_plain: that pass ran without regularisation; qvalid: q_hash describes plane cur
   unsigned bw_hash = 0u, q_hash = 0u;
   bool bw_plain = false, qvalid = false;
   long long ngc = 0;
@@ -940,20 +940,13 @@ struct Solver {
     const int ldg_ = ly.ldg;
     const unsigned nn = n * n, nm = n * m;
     lds_d* const ltrash = (lds_d*)zb + nzp;  // LDS sink (qz[0], dead during rollouts)
-    // Row t of the constraint table (ac), of [A B] (ab), and -- closed loop, for the gradient A_c' g left in Qz --
-    // columns t and 16 + t of the table (acx, acu) are read from LDS at every knot rather than held across the loop:
-    // 190 registers held for the whole rollout pushed the loop into scratch (each reload a vmcnt(0)).  Rows beyond
-    // Pn of Ac are zero or never count (on = false), the table's pad columns are zero.
+    // Row t of the constraint table (ac) is read from LDS at every knot rather than held across the loop (registers:
+    // a loop that spills reloads from scratch, each reload a vmcnt(0)); rows beyond Pn never count (on = false).
     const lds_d* acrow = (const lds_d*)Ac + (rows ? Tr * ldg_ : 0);
-    const lds_d* accol = (const lds_d*)Ac;
     const lds_d* abrow = (const lds_d*)G + Tn * ldg_;
-    const int lastrow = Pn > 0 ? Pn - 1 : 0;
     double ab[32];  // row t of [A B]: time-invariant dynamics keep it for the whole rollout, per-knot ones refill it
 #pragma unroll
     for (int c = 0; c < 32; ++c) ab[c] = abrow[c];
-    // Qz is written by the alpha = 1 trial only (a smaller step leaves the plane describing that trial: qvalid = false)
-    const bool wq = CLOSED && alpha == 1.0;
-    double* Qzi = P.Qz + (size_t)inst * N * nz;
     unsigned qh = 0u;
     double fT = LTV ? 0.0 : fk(0)[Tn];
     double J = 0.0, viol = 0.0;
@@ -1042,18 +1035,10 @@ struct Solver {
     for (int k = 0; k < N - 1; ++k) {
       const Ld d3 = ld(k + 3);
       kq1 = k_request(k + 2);
-      double ac[32], acx[16], acu[16];
+      double ac[32];
       if constexpr (ROWS) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) ac[c] = acrow[c];
-        if constexpr (CLOSED) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = r < Pn ? r : lastrow;  // rows beyond Pn: g_r = 0
-            acx[r] = accol[rr * ldg_ + Tn];
-            acu[r] = accol[rr * ldg_ + 16 + Tm];
-          }
-        }
       }
       double kp[16];
       if constexpr (CLOSED) {
@@ -1101,20 +1086,10 @@ struct Solver {
         viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
       }
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
-      if (CLOSED) {  // gradient of the AL cost at this knot and the active-set code, for the costate sweep
-        const double g = on ? d.lam + (act ? mu * v : 0.0) : 0.0;
-        double qx = cwx * (xb - d.xr), qu = cwu * (uv - d.ur);
-        box_grad(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx, qx);
-        box_grad(uv, cumax, cumin, d.luh, d.lul, isu & bx, qu);
-        if constexpr (ROWS) {
-          qx = RowDot<16>::run(acx, g, qx);
-          qu = RowDot<16>::run(acu, g, qu);
-        }
+      if (CLOSED) {  // active-set code of the knot at the trajectory produced (compared with the backward pass's by the costate sweep)
         const unsigned code = box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2) |
                               ((on & act) ? 16u : 0u);
         qh = hash_add(qh, code, k);
-        *((wq & isx) ? Qzi + (unsigned)k * nz + t : gtrash + t) = qx;
-        *((wq & isu) ? Qzi + (unsigned)k * nz + n + t : gtrash + t) = qu;
       }
       double xn = RowDot<16>::run(ab, xb, fT);
       xn = RowDot<16>::run(ab + 16, uv, xn);
@@ -1131,12 +1106,9 @@ struct Solver {
       d2 = d3;
     }
     *(isx ? Xd + (unsigned)(N - 1) * n + t : gtrash + t) = xb;
-    double ac[16], acx[16];
+    double ac[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      ac[c] = ROWS ? (double)acrow[c] : 0.0;
-      acx[c] = ROWS ? (double)accol[(c < Pn ? c : lastrow) * ldg_ + Tn] : 0.0;
-    }
+    for (int c = 0; c < 16; ++c) ac[c] = ROWS ? (double)acrow[c] : 0.0;
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
     // rows of the terminal knot see the state only
     const double v = ROWS ? RowDot<16>::run(ac, xb, d.bc) : 0.0;
@@ -1152,12 +1124,7 @@ struct Solver {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
       const bool bxT = box_at(N - 1);
-      const double g = on ? d.lam + (act ? mu * v : 0.0) : 0.0;
-      double qx = cwfx * (xb - d.xr);
-      box_grad(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT, qx);
-      qx = RowDot<16>::run(acx, g, qx);
       qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT) | ((on & act) ? 16u : 0u), N - 1);
-      *((wq & isx) ? Qzi + (unsigned)(N - 1) * nz + t : gtrash + t) = qx;
     }
     block_sync();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
@@ -1170,10 +1137,91 @@ struct Solver {
     return r;
   }
 
+  // First half of the costate sweep: l_x, l_u of every knot of plane cur (tracking cost, box terms, A_c' g of the generic
+  // rows: what expansion() computes) into the plane Qz.  No recursion here: the knots are independent, their
+  // operands are requested one knot ahead.
+  template <bool ROWS>
+  __device__ __forceinline__ void grad_pass() {
+    int t = T;
+    asm volatile("" : "+v"(t));
+    const bool isx = t < n, isu = t < m, isr = ROWS && t < Pn;
+    const unsigned Tn = isx ? t : n - 1, Tm = isu ? t : m - 1, Tr = isr ? t : 0;
+    const int ldg_ = ly.ldg;
+    double* gtrash = P.trash + (size_t)inst * 64;
+    double* Qzi = P.Qz + (size_t)inst * N * nz;
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    const int* ctp = ROWS ? P.ctype : (const int*)gtrash;
+    const double* lcp = ROWS ? Lci : gtrash;
+    const double* bcp = ROWS ? bconi : gtrash;
+    const unsigned rstride = ROWS ? (unsigned)Pn : 0u;
+    const lds_d* acrow = (const lds_d*)Ac + (ROWS ? Tr * ldg_ : 0);
+    const lds_d* accol = (const lds_d*)Ac;
+    const int lastrow = Pn > 0 ? Pn - 1 : 0;
+    struct Qk {  // per-lane operands of a knot
+      double xs, us, xr, ur, lxh, lxl, luh, lul, lam, bc;
+      int ct;
+    };
+    auto ldq = [&](int kk) __attribute__((always_inline)) {
+      const unsigned k = kk < N - 1 ? kk : N - 1;
+      const unsigned ku = k < (unsigned)(N - 1) ? k : N - 2;
+      Qk q;
+      q.xs = ldg(Xs, k * n + Tn);
+      q.xr = ldg(Xri, (kref + k) * n + Tn);
+      q.lxh = ldg(Lbi, (k * 2 + 0) * nz + Tn);
+      q.lxl = ldg(Lbi, (k * 2 + 1) * nz + Tn);
+      q.us = ldg(Us, ku * m + Tm);
+      q.ur = ldg(Uri, (kref + ku) * m + Tm);
+      q.luh = ldg(Lbi, (ku * 2 + 0) * nz + n + Tm);
+      q.lul = ldg(Lbi, (ku * 2 + 1) * nz + n + Tm);
+      q.ct = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(ctp) + ((k * rstride + Tr) << 2));
+      q.lam = ldg(lcp, k * rstride + Tr);
+      q.bc = ldg(bcp, k * rstride + Tr);
+      return q;
+    };
+    Qk qs[2];
+    qs[0] = ldq(0);
+    auto knot = [&](auto uc, int k) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc)::value;
+      const bool live = k < N, term = k >= N - 1;
+      qs[U ^ 1] = ldq(k + 1);
+      const Qk& q = qs[U];
+      const bool bx = box_at(k < N ? k : N - 1);
+      const double x = isx ? q.xs : 0.0, u = (isu & !term) ? q.us : 0.0;
+      double qx = (term ? cwfx : cwx) * (x - q.xr), qu = cwu * (u - q.ur);
+      box_grad(x, cxmax, cxmin, q.lxh, q.lxl, isx & bx, qx);
+      box_grad(u, cumax, cumin, q.luh, q.lul, isu & bx & !term, qu);
+      if constexpr (ROWS) {
+        double ac[32], acx[16], acu[16];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ac[c] = acrow[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = r < Pn ? r : lastrow;  // rows beyond Pn: g_r = 0
+          acx[r] = accol[rr * ldg_ + Tn];
+          acu[r] = accol[rr * ldg_ + 16 + Tm];
+        }
+        double v = RowDot<16>::run(ac, x, q.bc);
+        v = RowDot<16>::run(ac + 16, u, v);  // u = 0 at the terminal knot: its rows see the state only
+        const bool on = isr & (q.ct != 0), act = (q.ct == 1) | (v >= 0.0) | (q.lam > 0.0);
+        const double g = on ? q.lam + (act ? mu * v : 0.0) : 0.0;
+        qx = RowDot<16>::run(acx, g, qx);
+        qu = RowDot<16>::run(acu, g, qu);
+      }
+      *((live & isx) ? Qzi + (unsigned)k * nz + t : gtrash + t) = qx;
+      *((live & isu & !term) ? Qzi + (unsigned)k * nz + n + t : gtrash + t) = qu;
+    };
+    for (int k = 0; k < N; k += 2) {
+      knot(std::integral_constant<int, 0>{}, k);
+      knot(std::integral_constant<int, 1>{}, k + 1);
+    }
+    block_sync();  // Qz is read back by the recursion
+  }
+
   // Costate sweep (default mode; the problems of the row rollouts): lambda_N = l_x(N), lambda_k = l_x(k) + A_k' lambda_{k+1},
   // g_k = l_u(k) + B_k' lambda_{k+1}, d_k = -Quu_k^-1 g_k -- the first-order part of the backward pass, ~400
   // instructions per knot instead of ~3000.  l_x, l_u at the current trajectory (tracking cost, box terms, A_c' g of
-  // the generic rows) were left in Qz by the alpha = 1 rollout that produced it; Quu_k = L D L' is the factor the last
+  // the generic rows) were written to Qz by grad_pass() just before; Quu_k = L D L' is the factor the last
   // backward pass stored (same active set = same Quu).  Inside a fixed active set the problem is quadratic, and by
   // induction over the knots every feedforward term of a new backward pass vanishes iff every d_k of this recursion
   // does.  Returns true if |d_k,a| <= 1e-9 (1 + |u_k,a|) at every knot -- the test of the confirmation iterations.
@@ -2018,15 +2066,15 @@ struct Solver {
     }
     double J_prev = r0.J, J = r0.J;
     cmax = r0.cmax;
-    qvalid = false;  // the duals / the penalty may have changed since Qz was written
+    qvalid = false;  // the duals / the penalty may have changed since the hash was taken
     bw_plain = false;
     for (int it = 0; it < o.iterations_inner; ++it) {
       double dV1 = 0.0, dV2 = 0.0;
       bool gave_up = false;
       // Confirmation by the costate sweep (default mode; altro_opts.strict = 1 never takes it): from the second
-      // iteration of an inner solve on, if the last backward pass ran without regularisation, the trajectory came out of an
-      // alpha = 1 rollout (its gradient is in Qz) and crossed no active-set boundary on the way, the first-order sweep
-      // decides whether a backward pass here would return feedforward terms at rounding level.  If so the
+      // iteration of an inner solve on, if the last backward pass ran without regularisation and the accepted step crossed
+      // no active-set boundary (hashes of the pass and of the rollout), the first-order sweep decides whether a
+      // backward pass here would return feedforward terms at rounding level.  If so the
       // iteration is booked as converged without that pass; the gains in memory are its K, the feedforward terms
       // are set to zero.
       bool gconf = false;
@@ -2039,6 +2087,7 @@ struct Solver {
         if (tryg) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
+          if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
           gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
           WSTAMP(t_td += wstamp() - ts;)
           if (gconf) {
@@ -2070,7 +2119,7 @@ struct Solver {
       J = __builtin_inf();
       int ls = 0;
       bool accepted = true;
-      unsigned qh1 = 0u;
+      unsigned qh_acc = 0u;
       // Default-mode shortcuts, the ones of solve_dpp16.h (altro_opts.strict = 1 takes none of them).  Confirmation
       // iteration: every feedforward term of the backward pass is at rounding level, so the rollout, its line search
       // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
@@ -2094,12 +2143,8 @@ struct Solver {
         WSTAMP(const long long ts = wstamp();)
         const RollOut r = rollout(false, alpha);
         WSTAMP(t_ro += wstamp() - ts;)
-        if (ls == 0) {
-          nro++;
-          qh1 = r.qh;
-        } else {
-          ntr++;
-        }
+        if (ls == 0) nro++; else ntr++;
+        qh_acc = r.qh;  // (the last trial run is the accepted one, if any is)
         if (r.limit) { ls++; alpha *= 0.5; continue; }
         J = r.J;
         cm = r.cmax;
@@ -2114,9 +2159,11 @@ struct Solver {
       }
       if (accepted) alpha *= 2.0;
       if (confirm) alpha = 1.0;
-      if (!confirm) {  // Qz describes the new plane only if the alpha = 1 trial was the one accepted
+      if (!confirm) {  // the active-set hash of the trajectory now in plane cur: that of the accepted trial.  Only a full
+        // step is followed by a sweep: inside an active set it lands on the minimiser of the quadratic model, a damped one
+        // does not, and a sweep that does not confirm costs a quarter of the backward pass it fails to replace
         qvalid = accepted && alpha == 1.0;
-        q_hash = qh1;
+        q_hash = qh_acc;
       }
       if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
       if (accepted) cur ^= 1;  // copy_trajectories!
