@@ -1139,7 +1139,7 @@ struct Solver {
 
   // First half of the costate sweep: l_x, l_u of every knot of plane cur (tracking cost, box terms, A_c' g of the generic
   // rows: what expansion() computes) into the plane Qz.  No recursion here: the knots are independent, their
-  // operands are requested one knot ahead.
+  // operands are requested three knots ahead.
   template <bool ROWS>
   __device__ __forceinline__ void grad_pass() {
     int t = T;
@@ -1179,12 +1179,14 @@ struct Solver {
       q.bc = ldg(bcp, k * rstride + Tr);
       return q;
     };
-    Qk qs[2];
+    Qk qs[4];  // operands three knots ahead (a knot here is ~400 instructions, less than a memory round trip)
     qs[0] = ldq(0);
+    qs[1] = ldq(1);
+    qs[2] = ldq(2);
     auto knot = [&](auto uc, int k) __attribute__((always_inline)) {
       constexpr int U = decltype(uc)::value;
       const bool live = k < N, term = k >= N - 1;
-      qs[U ^ 1] = ldq(k + 1);
+      qs[(U + 3) & 3] = ldq(k + 3);
       const Qk& q = qs[U];
       const bool bx = box_at(k < N ? k : N - 1);
       const double x = isx ? q.xs : 0.0, u = (isu & !term) ? q.us : 0.0;
@@ -1211,9 +1213,11 @@ struct Solver {
       *((live & isx) ? Qzi + (unsigned)k * nz + t : gtrash + t) = qx;
       *((live & isu & !term) ? Qzi + (unsigned)k * nz + n + t : gtrash + t) = qu;
     };
-    for (int k = 0; k < N; k += 2) {
+    for (int k = 0; k < N; k += 4) {
       knot(std::integral_constant<int, 0>{}, k);
       knot(std::integral_constant<int, 1>{}, k + 1);
+      knot(std::integral_constant<int, 2>{}, k + 2);
+      knot(std::integral_constant<int, 3>{}, k + 3);
     }
     block_sync();  // Qz is read back by the recursion
   }
