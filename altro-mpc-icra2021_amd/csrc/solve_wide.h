@@ -2085,9 +2085,6 @@ struct Solver {
       if constexpr (SM) {
         const bool tryg = !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && row_rollouts() && !wave_any(q_hash != bw_hash) &&
                           (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
-#ifdef ALTRO_DEBUG_SWEEP
-        if (!o.strict && it >= 1) ntr += 1000000 * ((bw_plain ? 1 : 0) + (qvalid ? 10 : 0) + (rho == 0.0 ? 100 : 0) + (!wave_any(q_hash != bw_hash) ? 1000 : 0));
-#endif
         if (tryg) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)

@@ -39,7 +39,7 @@ print("quadruped N=%d B=%d: %.1f ms/step = %.0f solves/s; per instance-solve (Mc
     N, B, 1e3 * dt / S, B * S / dt, tb.mean() / S / 1e6, tg.mean() / S / 1e6, tr.mean() / S / 1e6, ni.sum() / ns.sum(), ni.max()))
 if "stamps" not in os.environ.get("ALTRO_HIP_LIB", ""):
     print("   counters per instance-solve (plain build): backward passes %.2f  rollouts %.2f  extra line-search trials %.2f" % (tb.mean() / S, tr.mean() / S, tg.mean() / S))
-print("   costate-confirmed iterations per instance-solve %.3f; debug word (extra trials counter) mean %.0f" % (altro.confirm_counter(mp.solver).mean() / S, tg.mean() / S))
+print("   costate-confirmed iterations per instance-solve %.3f" % (altro.confirm_counter(mp.solver).mean() / S))
 st = altro.stats(mp.solver)
 print("   backward segments (Mcycles per instance over %d steps): expansion %.3f  qv+gemms+rows %.3f  factor+solve %.3f  S update, gains %.3f" % ((S,) + tuple(st.cost_trace[:, 12 + i].mean() / 1e6 for i in range(4))))
 print("   whole run %.3f  dual updates %.3f  plant step + shift %.3f  todorov %.3f (Mcycles per instance over %d steps)" % (tuple(st.cost_trace[:, 8 + i].mean() / 1e6 for i in range(4)) + (S,)))
