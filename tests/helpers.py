@@ -83,7 +83,10 @@ def rocket_oracle(O, rp, x0, opts, Xref=None, Uref=None, U0=None, constraints=No
     s.set_controls(rp.U0 if U0 is None else U0)
     s.con_ids = []
     for c in (rp.constraints if constraints is None else constraints):
-        s.con_ids.append(s.add_affine(c.kind, c.sense, c.A, c.b, c.k_first, c.k_last))
+        if c.A is None:        # a BOX spec
+            s.con_ids.append(s.add_box(c.zmin, c.zmax, c.k_first, c.k_last))
+        else:
+            s.con_ids.append(s.add_affine(c.kind, c.sense, c.A, c.b, c.k_first, c.k_last))
     s.set_opts(O.default_opts(**opts))
     return s
 

@@ -1159,6 +1159,44 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
+@pytest.mark.parametrize("n", [48, 20])
+def test_wide_kernel_generic_rows_on_large_states(oracle, n):
+    """Linear inequality rows, an equality at the terminal knot, a second-order cone and a control box on a random
+    linear model with n = 48 (the cooperative four-wave blocks: the constraint products A_c' D A_c go through the
+    helper waves too) and n = 20 (one wave per block, same code): cold solve and two warm solves against the oracle."""
+    m, N, B, dt = 4, 15, 3, 0.1
+    pbr = altro.problems.gen_random_linear_batch(1, n=n, m=m, N=N, steps=1, seed=61)
+    rng = np.random.default_rng(62 + n)
+    nz = n + m
+    cons = []
+    Al = np.zeros((3, nz)); Al[:, :n] = 0.3 * rng.standard_normal((3, n)); Al[:, n:] = rng.standard_normal((3, m))
+    cons.append(P.ConstraintSpec(P.LINEAR, P.INEQ, 0, N - 2, A=Al, b=-1.5 * np.ones(3)))          # A z - 1.5 <= 0
+    Ae = np.zeros((2, nz)); Ae[:, :n] = rng.standard_normal((2, n))
+    cons.append(P.ConstraintSpec(P.LINEAR, P.EQ, N - 1, N - 1, A=Ae, b=np.zeros(2)))              # terminal equality
+    As = np.zeros((3, nz)); As[0, n] = 1.0; As[1, n + 1] = 1.0; As[2, n + 2] = 0.0
+    cons.append(P.ConstraintSpec(P.SOC, P.INEQ, 0, N - 2, A=As, b=np.array([0.0, 0.0, 2.0])))       # |u_0, u_1| <= 2
+    zmin = np.r_[np.full(n, -np.inf), np.full(m, -2.5)]; zmax = np.r_[np.full(n, np.inf), np.full(m, 2.5)]
+    cons.append(P.ConstraintSpec(P.BOX, P.INEQ, 0, N - 2, zmin=zmin, zmax=zmax))
+    rp = P.RocketProblemData(n=n, m=m, N=N, dt=dt, A=pbr.A[0], Bm=pbr.Bm[0], f=np.zeros(n), Q=np.full(n, 10.0), R=np.full(m, 0.1),
+                             Qf=np.full(n, 10.0), xf=np.zeros(n), x0=np.zeros(n), U0=np.zeros((N - 1, m)), constraints=cons)
+    x0 = rng.standard_normal((B, n)) * 0.4
+    opts = dict(REF_OPTS, penalty_initial=10.0, penalty_scaling=10.0, iterations_outer=40)
+    sv = altro.ALTROSolver(altro.mpc.constrained_problem(rp, x0), altro.SolverOptions(**opts))
+    assert altro.wave_cycles(sv).size == 0
+    orcs = [rocket_oracle(oracle, rp, x0[b], opts) for b in range(B)]
+    for rep in range(3):
+        if rep:
+            x0 = x0 + 0.05 * rng.standard_normal(x0.shape)
+            altro.set_initial_state(sv, x0)
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b in range(B):
+            if rep:
+                orcs[b].set_initial_state(x0[b])
+            check_against_oracle(st, X, U, b, orcs[b], orcs[b].solve())
+        assert np.all(st.status == altro.SOLVE_SUCCEEDED) and (rep > 0 or st.iterations_outer.max() >= 2)   # feasible, and the rows were active
+
+
 @pytest.mark.parametrize("N", [3, 4, 5, 6])
 def test_wide_kernel_shortest_horizons(oracle, monkeypatch, N):
     """Horizons of 3..6 knots (3 is the ABI's minimum) on the one-wave-per-instance kernel, time-invariant and per-knot dynamics: the row
