@@ -16,7 +16,19 @@
 // use the ABI layouts directly, so this path needs no pack kernels.
 //
 // Semantics follow oracle/altro_oracle.c statement by statement; the line
-// search uses true closed-loop rollouts for every alpha, as the reference does.
+// search uses true closed-loop rollouts for every alpha, as the reference does.  In the default mode
+// (altro_opts.strict = 0) iterations that only confirm convergence are cut short as in the 16-lane kernels
+// (ilqr(): confirmation iterations, line-search early-outs, and for n, m <= 16 the costate sweep).
+//
+// Three instantiation families:
+//   * Solver<MC, SM = true>, n, m <= 16: every matrix of a knot is one 16 x 16 tile; compile-time leading dimensions,
+//     the knot's five products chained in registers, L D L' per lane, rollouts and the costate sweep in one
+//     16-lane DPP row (rollout_row, grad_pass, adjoint_row);
+//   * Solver<MC, false>, one wave per block: runtime tile loops (gemm_tn);
+//   * Solver<MC, false>, a cooperative block of four waves where LDS leaves room for one instance per CU (n >= 48):
+//     waves 1..3 take strips of the large products on command (coop_exec / coop_helper).
+// The lane index is made opaque at the start of every phase (phase_begin): without it LLVM hoists every
+// lane-dependent address of the kernel to its entry and the knot loops reload them from scratch.
 #pragma once
 #include <hip/hip_runtime.h>
 
