@@ -343,6 +343,49 @@ def test_quadruped_full_batch_properties_and_sampled_parity(oracle):
     assert np.array_equal(altro.states(mp2.solver), X[sub]) and np.array_equal(altro.controls(mp2.solver), U[sub])
 
 
+@pytest.mark.parametrize("n,B", [(16, 8192), (32, 8192), (48, 2048), (64, 2048)])
+def test_state_dim_sweep_full_batch_properties(oracle, n, B):
+    """BASELINE configs[3] at its per-GPU sizes: random_linear_mpc with m = 4, N = 50 and n = 16, 32 (8192 instances),
+    48, 64 (2048 instances: the cooperative four-wave blocks), four fused MPC steps.  Whole-batch properties after the
+    launch: every solve SOLVE_SUCCEEDED, |u| <= 3 to the constraint tolerance, the dynamics satisfied to rounding,
+    x_1 == x0 bit for bit, the reported c_max equal to the bound violation evaluated on the host; a strided sample
+    follows the oracle; instances are independent of the batch around them (a sub-batch reproduces them bit for bit)."""
+    m, N, S = 4, 50, 4
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=71)
+    mp = altro.mpc.BatchMPC(pb)
+    mp.initial_solve()
+    sample = [0, B // 2 + 1, B - 1]
+    orcs = {b: make_oracle(oracle, pb, b) for b in sample}
+    for o in orcs.values():
+        o.solve()
+    for i in range(S - 1):
+        mp.step(i)
+        for b, o in orcs.items():
+            mpc_update(o, pb, b, i)
+            o.solve()
+    mp.step(S - 1)
+    st, X, U, x0g = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()
+    for b, o in orcs.items():
+        mpc_update(o, pb, b, S - 1)
+        check_against_oracle(st, X, U, b, o, o.solve())
+    assert np.all(st.status == altro.SOLVE_SUCCEEDED)
+    assert np.array_equal(X[:, 0], x0g)
+    Xn = np.einsum("bij,bkj->bki", pb.A, X[:, :-1]) + np.einsum("bij,bkj->bki", pb.Bm, U)
+    assert np.abs(Xn - X[:, 1:]).max() <= 1e-11 * max(1.0, np.abs(X).max())
+    viol = np.maximum(np.abs(U) - pb.u_bnd, 0.0).reshape(B, -1).max(1)
+    assert viol.max() < REF_OPTS["constraint_tolerance"]
+    assert np.abs(viol - st.c_max).max() <= 1e-12
+    sub = np.array([1, B // 3, B - 2])
+    import copy
+    pb2 = copy.copy(pb)
+    pb2.A, pb2.Bm, pb2.Xtrack, pb2.Utrack, pb2.noise = pb.A[sub], pb.Bm[sub], pb.Xtrack[sub], pb.Utrack[sub], pb.noise[:, sub]
+    mp2 = altro.mpc.BatchMPC(pb2)
+    mp2.initial_solve()
+    mp2.run_async(S, first=0)
+    mp2.synchronize()
+    assert np.array_equal(altro.states(mp2.solver), X[sub]) and np.array_equal(altro.controls(mp2.solver), U[sub])
+
+
 def test_rocket_full_batch_properties(oracle):
     """BASELINE configs[2] at its own size: rocket landing with the three second-order cones, N_mpc = 100, batch 4096,
     fused device loop.  Whole-batch properties after every launch: thrust-magnitude, thrust-angle and glideslope
