@@ -1533,6 +1533,17 @@ struct Solver {
     return ((bh & ah) ? 1u : 0u) | ((bl & al) ? 2u : 0u);
   }
 
+  // box_expand with selects only: same values
+  __device__ __forceinline__ void box_expand_sel(double z, double zmx, double zmn, double lhi, double llo, bool on, double& q, double& h) const {
+    const double chi = z - zmx, clo = zmn - z;
+    const bool bh = on & (zmx < 1e300), bl = on & (zmn > -1e300);
+    const bool ah = (chi >= 0.0) | (lhi > 0.0), al = (clo >= 0.0) | (llo > 0.0);
+    q += bh ? lhi + (ah ? mu * chi : 0.0) : 0.0;
+    h += (bh & ah) ? mu : 0.0;
+    q -= bl ? llo + (al ? mu * clo : 0.0) : 0.0;
+    h += (bl & al) ? mu : 0.0;
+  }
+
   // gradient of the box terms of one element (what box_expand adds to q), branch-free
   __device__ __forceinline__ void box_grad(double z, double zmx, double zmn, double lhi, double llo, bool on, double& q) const {
     const double chi = z - zmx, clo = zmn - z;
@@ -1547,6 +1558,55 @@ struct Solver {
   __device__ __forceinline__ void expansion(int k, bool term, const KnotLd& d, unsigned& code) {
     const bool bx = box_at(k);
     code = box_code(d.xs, cxmax, cxmin, d.lxh, d.lxl, bx & (T < n)) | (box_code(d.us, cumax, cumin, d.luh, d.lul, bx & (T < m) & !term) << 2);
+    if constexpr (SM) {
+      // n, m <= 16, at most 16 linear rows in a resident table, a stage knot: the whole expansion in the first DPP row,
+      // lane T with x_T, u_T and row T of the table -- the row values A_c z + b and the gradient A_c' g take their vector
+      // operand from the other lanes by row broadcast instead of three LDS hand-overs with a barrier each.  Terms in
+      // the order of the LDS version below: bit-identical.  Branch-free (every lane executes the DPP instructions).
+      if (!term && Pn > 0 && Pn <= 16 && da_on_the_fly()) {
+        const bool isx = T < n, isu = T < m, isr = T < Pn;
+        const int Tn = isx ? T : n - 1, Tm = isu ? T : m - 1, Tr = isr ? T : 0, lastrow = Pn - 1;
+        const double x = isx ? d.xs : 0.0, u = isu ? d.us : 0.0;
+        double qx = cwx * (x - d.xr), hx = cwx, qu = cwu * (u - d.ur), hu = cwu;
+        box_expand_sel(x, cxmax, cxmin, d.lxh, d.lxl, isx & bx, qx, hx);
+        box_expand_sel(u, cumax, cumin, d.luh, d.lul, isu & bx, qu, hu);
+        const lds_d* acrow = (const lds_d*)Ac + Tr * ly.ldg;
+        const lds_d* accol = (const lds_d*)Ac;
+        double ac[32], acx[16], acu[16];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ac[c] = acrow[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = r < Pn ? r : lastrow;  // rows beyond Pn: g_r = 0
+          acx[r] = accol[rr * ly.ldg + Tn];
+          acu[r] = accol[rr * ly.ldg + 16 + Tm];
+        }
+        double v = RowDot<16>::run(ac, x, d.bc);
+        v = RowDot<16>::run(ac + 16, u, v);
+        const bool on = isr & (d.ct != 0), act = (d.ct == 1) | (v >= 0.0) | (d.lam > 0.0);
+        const double g = on ? d.lam + (act ? mu * v : 0.0) : 0.0;
+        const double D = (on & act) ? mu : 0.0;
+        code |= (on & act) ? 16u : 0u;
+        qx += RowDot<16>::run(acx, g, 0.0);
+        qu += RowDot<16>::run(acu, g, 0.0);
+        if (isx) {
+          zb[T] = x;
+          qz[T] = qx;
+          hz[T] = hx;
+        }
+        if (isu) {
+          zb[np + T] = u;
+          qz[np + T] = qu;
+          hz[np + T] = hu;
+        }
+        if (T < Pp) {
+          gr[T] = g;
+          Dr[T] = D;
+        }
+        wsync();
+        return;
+      }
+    }
     if (T < n) {
       const double x = d.xs;
       zb[T] = x;
