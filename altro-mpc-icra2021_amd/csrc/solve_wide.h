@@ -1558,7 +1558,8 @@ struct Solver {
   __device__ __forceinline__ void expansion(int k, bool term, const KnotLd& d, unsigned& code) {
     const bool bx = box_at(k);
     code = box_code(d.xs, cxmax, cxmin, d.lxh, d.lxl, bx & (T < n)) | (box_code(d.us, cumax, cumin, d.luh, d.lul, bx & (T < m) & !term) << 2);
-    if constexpr (SM) {
+    if constexpr (SM && MC >= 12) {  // (compiled into the m > 8 classes only: in the others its 64 transient registers pushed
+      // the backward pass of the box-only sweeps -- n = 16, (12,6) -- into scratch, -3 % there)
       // n, m <= 16, at most 16 linear rows in a resident table, a stage knot: the whole expansion in the first DPP row,
       // lane T with x_T, u_T and row T of the table -- the row values A_c z + b and the gradient A_c' g take their vector
       // operand from the other lanes by row broadcast instead of three LDS hand-overs with a barrier each.  Terms in
