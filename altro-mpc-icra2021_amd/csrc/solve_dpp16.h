@@ -820,7 +820,9 @@ struct Solver {
   // Plane cur^1 holds Z̄(1) from the alpha = 1 rollout.  trial_costs evaluates cost!, the
   // violation, the state/control limits and the "reproduces Z bit for bit" test for NA
   // consecutive step sizes alpha, alpha/2, ... in ONE streaming sweep (no gains, no serial chain).
-  static constexpr int NA = ALTRO_NA;
+  // (box-only kernels: a line search beyond alpha = 1 is rare -- 0.03 trials per solve on the headline -- and two trials
+  // per sweep keep its registers out of the way: +1-2 %; the conic kernels need six trials per iteration and prefer four)
+  static constexpr int NA = CONES ? ALTRO_NA : (ALTRO_NA < 2 ? ALTRO_NA : 2);
   struct Trials {
     double J[NA], cmax[NA];
     bool limit[NA], unchanged[NA];
