@@ -827,6 +827,7 @@ struct Solver {
     const double fT = fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
+    unsigned qh = 0u;  // active-set hash of the trajectory produced (costate sweep)
     double xb = isx ? x0i[Tn] : 0.0;
     struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
     auto ld = [&](int k) {
@@ -871,6 +872,7 @@ struct Solver {
       J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
       J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
+      qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2), k);
       const double xn = dot_lds(grow, 1, zb, 1, nzp, fT);
       wsync();
       xb = isx ? xn : 0.0;
@@ -881,6 +883,7 @@ struct Solver {
     wsync();
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
     lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));
+    qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & box_at(N - 1)), N - 1);
     if (CLOSED) {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
@@ -892,7 +895,7 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = CLOSED && !wave_any(chg);
     r.tiny = CLOSED && !wave_any(big);
-    r.qh = 0u;
+    r.qh = qh;
     return r;
   }
 
@@ -1384,6 +1387,108 @@ struct Solver {
     return !wave_any(dbig);
   }
 
+  // The costate sweep for the sizes of the generic instantiation (n > 16, m <= 16), time-invariant dynamics, box
+  // constraints only -- the class of rollout_simple, i.e. the state-dimension sweep.  Same recursion and the same test
+  // as adjoint_row, with the vectors in LDS: lambda_k (lane c: the c-th element, dot products down column c of the
+  // resident [A B]), g_k handed to every lane through LDS for the per-lane solve with the stored factor.  O(n^2) per
+  // knot against the O(n^3) of the backward pass it replaces: ~3 % of it at n = 64.
+  __device__ __forceinline__ bool adjoint_lds() {
+    constexpr int MP = MC > 0 ? MC : 4, FS = MP * (MP + 1) / 2;
+    const bool isx = T < n, isu = T < m;
+    const unsigned Tn = isx ? T : n - 1, Tm = isu ? T : m - 1;
+    const double* Xs = Xp(cur);
+    const double* Us = Up(cur);
+    const double* faci = P.fac + (size_t)inst * N * FS;
+    lds_d* const ltrash = (lds_d*)zb + nzp;
+    lds_d* const lamb[2] = {(lds_d*)sv, (lds_d*)dxv};      // lambda_{k+1} / lambda_k, zero beyond n
+    lds_d* const fpark[2] = {(lds_d*)S, (lds_d*)S + 136};  // the factor of knot k / k - 1
+    lds_d* const gvec = (lds_d*)qv;                         // g_k, zero beyond m
+    struct Qk {
+      double xs, us, xr, ur, lxh, lxl, luh, lul, f[3];
+    };
+    auto ldq = [&](int kk) __attribute__((always_inline)) {
+      const unsigned k = kk > 0 ? kk : 0;
+      Qk q;
+      q.xs = ldg(Xs, k * n + Tn);
+      q.xr = ldg(Xri, (kref + k) * n + Tn);
+      q.lxh = ldg(Lbi, (k * 2 + 0) * nz + Tn);
+      q.lxl = ldg(Lbi, (k * 2 + 1) * nz + Tn);
+      q.us = ldg(Us, k * m + Tm);
+      q.ur = ldg(Uri, (kref + k) * m + Tm);
+      q.luh = ldg(Lbi, (k * 2 + 0) * nz + n + Tm);
+      q.lul = ldg(Lbi, (k * 2 + 1) * nz + n + Tm);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const unsigned e = T + 64 * u;
+        q.f[u] = ldg(faci, k * FS + (e < FS ? e : FS - 1));
+      }
+      return q;
+    };
+    auto fpark_put = [&](const Qk& q, lds_d* st) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const unsigned e = T + 64 * u;
+        *(e < FS ? st + e : ltrash) = q.f[u];
+      }
+    };
+    // terminal knot: lambda_N = l_x(N)
+    {
+      const unsigned k = N - 1;
+      const double x = ldg(Xs, k * n + Tn);
+      double q = cwfx * (x - ldg(Xri, (kref + k) * n + Tn));
+      box_grad(x, cxmax, cxmin, ldg(Lbi, (k * 2 + 0) * nz + Tn), ldg(Lbi, (k * 2 + 1) * nz + Tn), isx & box_at(N - 1), q);
+      for (int c = T; c < np; c += 64) lamb[0][c] = (c < n) ? q : 0.0;
+    }
+    Qk qs[2];
+    qs[0] = ldq(N - 2);
+    fpark_put(qs[0], fpark[0]);
+    bool dbig = false;
+    wsync();
+    auto knot = [&](auto uc, int k) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc)::value;  // parity of the position: slots and LDS buffers alternate
+      const bool live = k >= 0;
+      qs[U ^ 1] = ldq(k - 1);
+      const Qk& q = qs[U];
+      const bool bx = box_at(k > 0 ? k : 0);
+      const double x = isx ? q.xs : 0.0, u = isu ? q.us : 0.0;
+      double qx = cwx * (x - q.xr), qu = cwu * (u - q.ur);
+      box_grad(x, cxmax, cxmin, q.lxh, q.lxl, isx & bx, qx);
+      box_grad(u, cumax, cumin, q.luh, q.lul, isu & bx, qu);
+      const double gx = dot_lds(G + Tn, ly.ldg, (const double*)lamb[U], 1, np, qx);        // l_x + A' lambda
+      double gu = dot_lds(G + np + Tm, ly.ldg, (const double*)lamb[U], 1, np, qu);        // l_u + B' lambda
+      gu = isu ? gu : 0.0;
+      if (T < 16) gvec[T] = gu;
+      for (int c = T; c < np; c += 64) lamb[U ^ 1][c] = (c < n) ? gx : 0.0;
+      fpark_put(qs[U ^ 1], fpark[U ^ 1]);
+      wsync();
+      double y[MP];
+#pragma unroll
+      for (int r = 0; r < MP; ++r) y[r] = gvec[r];
+      const lds_d* fk = fpark[U];
+#pragma unroll
+      for (int j = 0; j < MP; ++j)          // forward: L y = g
+#pragma unroll
+        for (int i = j + 1; i < MP; ++i) y[i] -= fk[i * (i + 1) / 2 + j] * y[j];
+#pragma unroll
+      for (int r = 0; r < MP; ++r) y[r] *= fk[r * (r + 1) / 2 + r];  // 1 / D
+#pragma unroll
+      for (int j = MP - 1; j >= 0; --j)     // backward: L' d = y
+#pragma unroll
+        for (int i = 0; i < j; ++i) y[i] -= fk[j * (j + 1) / 2 + i] * y[j];
+      double dsel = 0.0;
+#pragma unroll
+      for (int r = 0; r < MP; ++r) dsel = (T == r) ? y[r] : dsel;
+      dbig = dbig | (live & isu & !(fabs(dsel) <= 1e-9 * (1.0 + fabs(q.us))));
+      wsync();  // gvec and the factor buffer of this knot are free again
+    };
+    for (int k = N - 2; k >= 0; k -= 2) {
+      knot(std::integral_constant<int, 0>{}, k);
+      knot(std::integral_constant<int, 1>{}, k - 1);
+    }
+    // (sv and dxv are scratch again: the backward pass and the rollouts rewrite them before reading)
+    return !wave_any(dbig);
+  }
+
   // y[a] = element a of the row vector v (lanes a of this 16-lane row), a < MP
   template <int MP>
   static __device__ __forceinline__ void gather_row(double (&y)[MP], double v) {
@@ -1772,7 +1877,7 @@ struct Solver {
       for (int c = j + 1; c < MP; ++c) a[c][j] = f[c];
     }
     if (fail) return true;  // wave-uniform: every lane saw the same pivots
-    if (SM && T == 0) {  // the factor of this knot, for the costate sweep (78 doubles at MP = 12, one lane)
+    if (facout != nullptr && T == 0) {  // the factor of this knot, for the costate sweep (78 doubles at MP = 12, one lane)
 #pragma unroll
       for (int i = 0; i < MP; ++i) {
 #pragma unroll
@@ -2012,7 +2117,7 @@ struct Solver {
         if (MC > 0 && T >= m && T < mp) Huu[T * ldu + T] = 1.0;  // factor_solve_lane: identity in the pad rows
         wsync();
         if constexpr (MC > 0) {
-          if (factor_solve_lane<MC>(nullptr)) return true;
+          if (factor_solve_lane<MC>(P.fac + ((size_t)inst * N + k) * (MC * (MC + 1) / 2))) return true;
         } else {
           // Quu_reg = L D L' in place in LDS (unit L below the diagonal, D on it)
           for (int j = 0; j < m; ++j) {
@@ -2155,14 +2260,19 @@ struct Solver {
       // iteration is booked as converged without that pass; the gains in memory are its K, the feedforward terms
       // are set to zero.
       bool gconf = false;
-      if constexpr (SM) {
-        const bool tryg = !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && row_rollouts() && !wave_any(q_hash != bw_hash) &&
+      if constexpr (MC > 0) {
+        const bool can_sweep = SM ? row_rollouts() : (Pn == 0 && !P.ltv);
+        const bool tryg = !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && can_sweep && !wave_any(q_hash != bw_hash) &&
                           (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
         if (tryg) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
-          if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
-          gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
+          if constexpr (SM) {
+            if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
+            gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
+          } else {
+            gconf = adjoint_lds();
+          }
           WSTAMP(t_td += wstamp() - ts;)
           if (gconf) {
             ngc++;

@@ -82,8 +82,8 @@ def test_wide_kernel_strict_option_and_default_shortcuts(oracle, n, m, N):
             x0s.append(mp.x0()); u1s.append(altro.controls(mp.solver)[:, 0].copy()); its.append(st.iterations.copy()); sts.append(st.status.copy())
         nb, nr, ntr = altro.work_counters(mp.solver)
         ngc = altro.confirm_counter(mp.solver)
-        # the n, m <= 16 instantiation also settles confirmation iterations by the costate sweep (no backward pass)
-        assert (ngc.sum() > 0.3 * B * S and nb.sum() + ngc.sum() == np.array(its).sum()) if (strict == 0 and n <= 16) else ngc.sum() == 0
+        # confirmation iterations are settled by the costate sweep (no backward pass) in the default mode
+        assert (ngc.sum() > 0.3 * B * S and nb.sum() + ngc.sum() == np.array(its).sum()) if strict == 0 else ngc.sum() == 0
         runs.append((np.array(x0s), np.array(u1s), np.array(its), np.array(sts), float((nr + ntr).sum())))
     (xa, ua, ia, sa, ra), (xb, ub, ib, sb, rb) = runs
     assert np.array_equal(sa, sb) and np.all(sa == altro.SOLVE_SUCCEEDED)
