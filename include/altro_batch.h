@@ -117,8 +117,8 @@ typedef struct altro_opts {
    * 1: none of them, the reference's exact sequence (about half the throughput on BASELINE's headline workload).
    * The one-wave-per-instance kernel (sizes outside the 16-lane set, per-knot dynamics) takes (b) and the line-search
    * early-out the same way in the default mode and always re-symmetrises S; for n, m <= 16 (at most 16 linear rows,
-   * no cones) it also has a costate sweep (a), which solves for the feedforward terms with the factors of Quu the
-   * last backward pass stored and applies test (b) to them. */
+   * no cones) and for box-only time-invariant problems with n > 16, m <= 16 it also has a costate sweep (a), which
+   * solves for the feedforward terms with the factors of Quu the last backward pass stored and applies test (b) to them. */
   int32_t strict;
   /* Altro.SolverOptions.kickout_max_penalty (default false): with 0 the AL outer loop does not stop when the penalty
    * has reached penalty_max -- it goes on with dual updates at the cap until the constraints are satisfied or
