@@ -977,7 +977,7 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
 
 int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
   return guard(h, [&]() -> int32_t {
-    if (h && h->wide && o) { h->wide->o = *o; h->o = *o; return ALTRO_OK; }
+    if (h && h->wide && o) { h->wide->o = *o; h->wide->gains_valid = false; h->o = *o; return ALTRO_OK; }
     if (!h || !o) return ALTRO_ERR_INVALID_ARG;
     h->o = *o;
     return ALTRO_OK;

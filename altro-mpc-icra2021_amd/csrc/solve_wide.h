@@ -69,6 +69,8 @@ struct Params {
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
   long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf;
   double* Qz;           // [B][N][n+m] scratch of the costate sweep: gradient of the AL cost at every knot of plane cur
+  unsigned* bwst;       // [B][72] gain-reuse state between launches: hash per lane [64], bw_ok, bw_plain, bw_mu (2 words)
+  int reuse_ok;         // 0: a setter has changed the model / cost / constraints / options since the last launch
   double* fac;          // [B][N][MC (MC + 1) / 2] (n, m <= 16) L D L' factor of Quu_k of the last backward pass: strictly lower
                         // triangle of L and 1 / D on the diagonal, row-major packed (costate sweep)
   const double *noise, *noise_w;
@@ -337,6 +339,9 @@ struct Solver {
   // plane cur holds; bw_plain: that pass ran without regularisation; qvalid: q_hash describes plane cur
   unsigned bw_hash = 0u, q_hash = 0u;
   bool bw_plain = false, qvalid = false;
+  bool bw_ok = false;  // Kg and fac hold a backward pass that succeeded (generic class: kept across the solves of a launch)
+  double bw_mu = 0.0;  // the penalty it ran at
+  long long ngs = 0;   // iterations that took their gains from memory (no backward pass)
   long long ngc = 0;
   long long nbw, nro, ntr;
   long long t_bw = 0, t_ro = 0, t_gemm = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_du = 0, t_sh = 0, t_run = 0, t_td = 0;
@@ -1392,7 +1397,10 @@ struct Solver {
   // as adjoint_row, with the vectors in LDS: lambda_k (lane c: the c-th element, dot products down column c of the
   // resident [A B]), g_k handed to every lane through LDS for the per-lane solve with the stored factor.  O(n^2) per
   // knot against the O(n^3) of the backward pass it replaces: ~3 % of it at n = 64.
-  __device__ __forceinline__ bool adjoint_lds() {
+  // full = true: the first-order half of a whole iteration -- the gains K_k in memory stay (the caller has
+  // established that a backward pass here would reproduce them), the costate runs s_k = Qx + K_k' Qu, the
+  // feedforward terms d_k = -Quu_k^-1 Qu are written out and the expected decrease (dV1, dV2) is returned.
+  __device__ __forceinline__ bool adjoint_lds(bool full, double& dV1, double& dV2) {
     constexpr int MP = MC > 0 ? MC : 4, FS = MP * (MP + 1) / 2;
     const bool isx = T < n, isu = T < m;
     const unsigned Tn = isx ? T : n - 1, Tm = isu ? T : m - 1;
@@ -1443,6 +1451,8 @@ struct Solver {
     qs[0] = ldq(N - 2);
     fpark_put(qs[0], fpark[0]);
     bool dbig = false;
+    double dv1 = 0.0;
+    double* gtr = P.trash + (size_t)inst * 64 + T;
     wsync();
     auto knot = [&](auto uc, int k) __attribute__((always_inline)) {
       constexpr int U = decltype(uc)::value;  // parity of the position: slots and LDS buffers alternate
@@ -1458,9 +1468,23 @@ struct Solver {
       double gu = dot_lds(G + np + Tm, ly.ldg, (const double*)lamb[U], 1, np, qu);        // l_u + B' lambda
       gu = isu ? gu : 0.0;
       if (T < 16) gvec[T] = gu;
-      for (int c = T; c < np; c += 64) lamb[U ^ 1][c] = (c < n) ? gx : 0.0;
       fpark_put(qs[U ^ 1], fpark[U ^ 1]);
       wsync();
+      {  // s_k = Qx + K_k' Qu (with d = 0, the confirmation test, the second term is at rounding level: it is left out)
+        double sx = gx;
+        if (full) {
+          const unsigned kk = k > 0 ? k : 0;
+          double kc[16], gq[16];
+#pragma unroll
+          for (int a_ = 0; a_ < 16; ++a_) {
+            kc[a_] = ldg(Kgi, kk * (unsigned)(n * m) + Tn * m + (a_ < m ? a_ : m - 1));
+            gq[a_] = gvec[a_];  // zero beyond m
+          }
+#pragma unroll
+          for (int a_ = 0; a_ < 16; ++a_) sx += kc[a_] * gq[a_];
+        }
+        for (int c = T; c < np; c += 64) lamb[U ^ 1][c] = (c < n) ? sx : 0.0;
+      }
       double y[MP];
 #pragma unroll
       for (int r = 0; r < MP; ++r) y[r] = gvec[r];
@@ -1479,6 +1503,10 @@ struct Solver {
 #pragma unroll
       for (int r = 0; r < MP; ++r) dsel = (T == r) ? y[r] : dsel;
       dbig = dbig | (live & isu & !(fabs(dsel) <= 1e-9 * (1.0 + fabs(q.us))));
+      if (full) {
+        *((live & isu) ? dgi + (unsigned)(k > 0 ? k : 0) * m + T : gtr) = 0.0 - dsel;
+        dv1 -= (live & isu) ? dsel * gu : 0.0;
+      }
       wsync();  // gvec and the factor buffer of this knot are free again
     };
     for (int k = N - 2; k >= 0; k -= 2) {
@@ -1486,6 +1514,11 @@ struct Solver {
       knot(std::integral_constant<int, 1>{}, k - 1);
     }
     // (sv and dxv are scratch again: the backward pass and the rollouts rewrite them before reading)
+    if (full) {
+      block_sync();  // the feedforward terms are read by the rollout
+      dV1 = wave_sum(dv1);
+      dV2 = -0.5 * dV1;
+    }
     return !wave_any(dbig);
   }
 
@@ -2248,11 +2281,35 @@ struct Solver {
     }
     double J_prev = r0.J, J = r0.J;
     cmax = r0.cmax;
-    qvalid = false;  // the duals / the penalty may have changed since the hash was taken
-    bw_plain = false;
+    // Gain reuse (default mode; n > 16, box-only, time-invariant: a first-order pass is ~5 % of a backward pass there).
+    // Inside a fixed active set and penalty the problem is LQ: K_k and Quu_k do not depend on the trajectory, so if the
+    // pass whose gains and factors are in memory ran at this penalty, without regularisation, and saw the active set the
+    // trajectory in plane cur has (hashes), a new pass would return the same K -- also across the MPC solves of a
+    // launch (60-67 % of the headline-type solves end with the active set they started with).  Such an iteration
+    // takes K from memory and its feedforward terms and expected decrease from adjoint_lds(full).
+    constexpr bool kReuse = MC > 0 && !SM;
+    const bool reuse_class = kReuse && !o.strict && Pn == 0 && !P.ltv;
+    if (reuse_class) {
+      q_hash = r0.qh;  // the open-loop rollout's hash of plane cur, with the current duals
+      qvalid = true;
+    } else {
+      qvalid = false;  // the duals / the penalty may have changed since the hash was taken
+      bw_plain = false;
+    }
     for (int it = 0; it < o.iterations_inner; ++it) {
       double dV1 = 0.0, dV2 = 0.0;
       bool gave_up = false;
+      bool swept = false;
+      if constexpr (kReuse) {
+        if (reuse_class && bw_ok && bw_plain && qvalid && rho == 0.0 && mu == bw_mu && !wave_any(q_hash != bw_hash)) {
+          phase_begin();
+          WSTAMP(const long long ts = wstamp();)
+          dtiny = adjoint_lds(true, dV1, dV2);
+          WSTAMP(t_td += wstamp() - ts;)
+          swept = true;
+          ngs++;
+        }
+      }
       // Confirmation by the costate sweep (default mode; altro_opts.strict = 1 never takes it): from the second
       // iteration of an inner solve on, if the last backward pass ran without regularisation and the accepted step crossed
       // no active-set boundary (hashes of the pass and of the rollout), the first-order sweep decides whether a
@@ -2262,8 +2319,8 @@ struct Solver {
       bool gconf = false;
       if constexpr (MC > 0) {
         const bool can_sweep = SM ? row_rollouts() : (Pn == 0 && !P.ltv);
-        const bool tryg = !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && can_sweep && !wave_any(q_hash != bw_hash) &&
-                          (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
+        const bool tryg = !swept && !(kReuse && reuse_class) && !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && can_sweep &&
+                          !wave_any(q_hash != bw_hash) && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
         if (tryg) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
@@ -2271,7 +2328,7 @@ struct Solver {
             if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
             gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
           } else {
-            gconf = adjoint_lds();
+            gconf = adjoint_lds(false, dV1, dV2);
           }
           WSTAMP(t_td += wstamp() - ts;)
           if (gconf) {
@@ -2282,7 +2339,7 @@ struct Solver {
           }
         }
       }
-      while (!gconf) {  // regularisation restarts
+      while (!gconf && !swept) {  // regularisation restarts
         const bool plain = rho == 0.0;
         WSTAMP(const long long ts = wstamp();)
         const bool fail = backward(dV1, dV2);
@@ -2291,13 +2348,16 @@ struct Solver {
         block_sync();  // phase end: gains written to global memory are read by other lanes in the rollout
         if (!fail) {
           bw_plain = plain;
+          bw_ok = true;
+          bw_mu = mu;
           break;
         }
+        bw_ok = false;  // (a failed pass has overwritten part of the gains)
         if (rho >= o.bp_reg_max) { gave_up = true; break; }
         reg_update(true);
       }
       if (gave_up) { status = ALTRO_NO_PROGRESS; break; }
-      if (!gconf) reg_update(false);
+      if (!gconf && !swept) reg_update(false);
       // forwardpass!
       double alpha = 1.0, z = -1.0, cm = 0.0;
       J = __builtin_inf();
@@ -2309,6 +2369,12 @@ struct Solver {
       // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
       // the outcome -- the iteration is booked as converged on the trajectory it holds.
       const bool confirm = gconf || (!o.strict && dtiny && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev))));
+      if (confirm && swept) {  // the confirmed iteration ran no backward pass: its feedforward terms are zero
+        ngc++;
+        for (int k = 0; k < N - 1; ++k)
+          if (T < m) dgi[(size_t)k * m + T] = 0.0;
+        block_sync();
+      }
       if (confirm) {
         J = J_prev;
         cm = cmax;
@@ -2344,10 +2410,15 @@ struct Solver {
       if (accepted) alpha *= 2.0;
       if (confirm) alpha = 1.0;
       if (!confirm) {  // the active-set hash of the trajectory now in plane cur: that of the accepted trial.  Only a full
-        // step is followed by a sweep: inside an active set it lands on the minimiser of the quadratic model, a damped one
-        // does not, and a sweep that does not confirm costs a quarter of the backward pass it fails to replace
-        qvalid = accepted && alpha == 1.0;
-        q_hash = qh_acc;
+        // step is followed by a confirmation sweep: inside an active set it lands on the minimiser of the quadratic model, a
+        // damped one does not, and a sweep that does not confirm costs a quarter of the backward pass it fails to replace
+        // (the gain-reuse class sweeps after any accepted step: there the pass always yields the iteration)
+        if (kReuse && reuse_class) {
+          if (accepted) q_hash = qh_acc;
+        } else {
+          qvalid = accepted && alpha == 1.0;
+          q_hash = qh_acc;
+        }
       }
       if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
       if (accepted) cur ^= 1;  // copy_trajectories!
@@ -2525,6 +2596,13 @@ struct Solver {
     mu = P.mu[inst];
     kref = P.kref;
     nbw = nro = ntr = 0;
+    {  // the gain-reuse state of the previous launch (one launch of K steps and K launches of one step decide alike)
+      const unsigned* st = P.bwst + (size_t)inst * 72;
+      bw_hash = st[T];
+      bw_ok = P.reuse_ok != 0 && st[64] != 0u;
+      bw_plain = st[65] != 0u;
+      bw_mu = __hiloint2double((int)st[67], (int)st[66]);
+    }
     long long nsolve = 0, nit = 0, nok = 0;
     if (!P.ltv) load_dyn(0);                                   // time-invariant dynamics stay resident in LDS
     if (Pn > 0 && P.con_static) build_static_Ac();           // and so does a time-invariant constraint table
@@ -2569,7 +2647,17 @@ struct Solver {
       P.n_solves[inst] += nsolve;
       P.n_iters[inst] += nit;
       P.n_ok[inst] += nok;
-      P.n_gconf[inst] += ngc;
+      P.n_gconf[inst] += (ngs > 0 ? ngs : ngc);  // iterations that ran no backward pass
+    }
+    {
+      unsigned* st = P.bwst + (size_t)inst * 72;
+      st[T] = bw_hash;
+      if (T == 0) {
+        st[64] = bw_ok ? 1u : 0u;
+        st[65] = bw_plain ? 1u : 0u;
+        st[66] = (unsigned)__double2loint(bw_mu);
+        st[67] = (unsigned)__double2hiint(bw_mu);
+      }
     }
     coop_quit();  // releases the helper waves of a cooperative block: the ONLY exit of run(), reached on every path
   }

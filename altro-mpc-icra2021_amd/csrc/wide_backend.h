@@ -56,6 +56,8 @@ struct WideBackend {
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
+  unsigned* bwst = nullptr;   // [B][72] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
+  bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
   std::vector<hipEvent_t> bench_ev;
   int *cur = nullptr, *ctype = nullptr, *rowk0 = nullptr, *rowk1 = nullptr, *rowc0 = nullptr, *rowcp = nullptr, *iters = nullptr, *iters_outer = nullptr,
@@ -120,7 +122,7 @@ struct WideBackend {
 #define DA_(p, c) if ((rc = dalloc(&p, (c)))) return rc
     DA_(wd, z); DA_(wf, n); DA_(zmin, z); DA_(zmax, z);
     DA_(x0, B * n); DA_(X, B * 2 * N * n); DA_(U, B * 2 * (N - 1) * m); DA_(cur, B);
-    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1);
+    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 72);
     DA_(iters, B); DA_(iters_outer, B); DA_(status, B); DA_(cost, B); DA_(cmax, B);
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
     DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B); DA_(n_gconf, B);
@@ -143,7 +145,7 @@ struct WideBackend {
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
-                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, fac};
+                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, fac, bwst};
     for (void* p : ptrs)
       if (p) hipFree(p);
     ring.destroy();
@@ -176,6 +178,7 @@ struct WideBackend {
   }
 
   int set_dynamics(const double* A_, const double* B_, const double* f_, int per_knot, int per_instance) {
+    gains_valid = false;
     const int rc = upload_dynamics(A_, B_, f_, per_knot ? (size_t)(d.N - 1) : 1, per_instance);
     if (rc) return rc;
     ltv = per_knot != 0;
@@ -186,6 +189,7 @@ struct WideBackend {
 
   // altro_mpc_set_dynamics_track: see include/altro_batch.h
   int mpc_set_dynamics_track(const double* A_, const double* B_, const double* f_, int nblocks, int step_stride, int per_instance) {
+    gains_valid = false;
     if (nblocks < d.N - 1 || (step_stride != 1 && step_stride != d.N - 1)) WFAIL(ALTRO_ERR_INVALID_ARG, "bad dynamics track shape");
     const int rc = upload_dynamics(A_, B_, f_, (size_t)nblocks, per_instance);
     if (rc) return rc;
@@ -198,6 +202,7 @@ struct WideBackend {
   bool dyn_covers(int kref_) const { return !ltv || (long long)kref_ * dyn_step_stride + (d.N - 1) <= (long long)dyn_blocks; }
 
   int set_tracking_cost(const double* Qd, const double* Rd, const double* Qfd, double dt) {
+    gains_valid = false;
     if (!Qd || !Rd || !Qfd || !(dt > 0.0)) return ALTRO_ERR_INVALID_ARG;
     WCHK(hipSetDevice(device));
     std::vector<double> w(nz());
@@ -251,6 +256,7 @@ struct WideBackend {
   }
 
   int update_constraint_data(int con_id, const double* A_, const double* b_) {
+    gains_valid = false;
     Block* bl = find(con_id);
     if (!bl) WFAIL(ALTRO_ERR_INVALID_ARG, "no such LINEAR constraint");
     const size_t nb = (bl->per_knot ? (size_t)(bl->k1 - bl->k0 + 1) : 1) * (bl->per_instance ? (size_t)d.batch : 1);
@@ -414,7 +420,7 @@ struct WideBackend {
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
-    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.Qz = Qz; p.fac = fac;
+    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = gains_valid ? 1 : 0;
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
@@ -462,6 +468,7 @@ struct WideBackend {
     WCHK(hipEventRecord(h0, stream));
     hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes())), lds_bytes(), stream, params(), mpc, first_step, nsteps);
     WCHK(hipGetLastError());
+    gains_valid = true;  // (until a setter changes something the stored gains depend on)
     WCHK(hipEventRecord(h1, stream));
     WCHK(hipEventRecord(ev1, stream));
     timed = true;
