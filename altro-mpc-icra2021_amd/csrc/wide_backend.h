@@ -420,7 +420,7 @@ struct WideBackend {
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
-    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = gains_valid ? 1 : 0;
+    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = (gains_valid || getenv("ALTRO_DEBUG_KEEP_GAINS")) ? 1 : 0;  // (the switch exists to show that the tests notice stale gains)
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;

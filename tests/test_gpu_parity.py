@@ -1202,6 +1202,49 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
+def test_wide_kernel_gain_reuse_is_dropped_when_the_model_or_the_options_change(oracle):
+    """n > 16, box-only, time-invariant: in the default mode iterations whose active set and penalty match the stored
+    backward pass take their gains from memory, also across launches.  A new model (set_dynamics) or new options
+    (set_options: another penalty) between two solves must drop them: the solves after the change still follow the
+    oracle driven through the same calls -- with stale gains the iterate path (cost trace, counts) differs: the test
+    fails under ALTRO_DEBUG_KEEP_GAINS=1, the diagnostic switch that keeps them."""
+    B, n, m, N = 4, 24, 4, 30
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=1, seed=81)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    rng = np.random.default_rng(82)
+    prob.x0 = prob.x0 + 0.3 * rng.standard_normal(prob.x0.shape)
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**REF_OPTS))
+    assert altro.wave_cycles(sv).size == 0
+    orcs = [make_oracle(oracle, pb, b) for b in range(B)]
+    for b, o in enumerate(orcs):
+        o.set_initial_state(prob.x0[b])
+
+    def both(tag):
+        altro.solve(sv)
+        st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+        for b, o in enumerate(orcs):
+            check_against_oracle(st, X, U, b, o, o.solve())
+        return int(altro.confirm_counter(sv).sum())
+
+    both("cold")
+    x1 = prob.x0 + 0.05 * rng.standard_normal(prob.x0.shape)
+    altro.set_initial_state(sv, x1)
+    for b, o in enumerate(orcs):
+        o.set_initial_state(x1[b])
+    reused = both("warm")                       # same model: iterations without a backward pass
+    assert reused > 0
+    A2 = pb.A * 0.97
+    altro.set_dynamics(sv, altro.LinearModel(A2, pb.Bm, None, dt=pb.dt))
+    for b, o in enumerate(orcs):
+        o.set_dynamics(A2[b], pb.Bm[b])
+    both("new model")
+    opts2 = dict(REF_OPTS, penalty_initial=50.0)
+    altro.set_options(sv, **opts2)
+    for o in orcs:
+        o.set_opts(oracle.default_opts(**opts2))
+    both("new penalty")
+
+
 @pytest.mark.parametrize("n", [48, 20])
 def test_wide_kernel_generic_rows_on_large_states(oracle, n):
     """Linear inequality rows, an equality at the terminal knot, a second-order cone and a control box on a random
