@@ -118,7 +118,11 @@ typedef struct altro_opts {
    * The one-wave-per-instance kernel (sizes outside the 16-lane set, per-knot dynamics) takes (b) and the line-search
    * early-out the same way in the default mode and always re-symmetrises S; for n, m <= 16 (at most 16 linear rows,
    * no cones) and for box-only time-invariant problems with n > 16, m <= 16 it also has a costate sweep (a), which
-   * solves for the feedforward terms with the factors of Quu the last backward pass stored and applies test (b) to them. */
+   * solves for the feedforward terms with the factors of Quu the last backward pass stored and applies test (b) to them.
+   * For the n > 16 class it goes one step further (gain reuse): any iteration whose active set and penalty are those of
+   * the stored pass takes its gains K from memory -- inside a fixed active set they do not depend on the trajectory --
+   * and only its feedforward terms from that first-order pass; dynamics, cost, constraint data and options setters
+   * drop the stored pass. */
   int32_t strict;
   /* Altro.SolverOptions.kickout_max_penalty (default false): with 0 the AL outer loop does not stop when the penalty
    * has reached penalty_max -- it goes on with dual updates at the cap until the constraints are satisfied or
