@@ -34,7 +34,7 @@ EXPORTS = [
     "altro_mpc_set_noise_model", "altro_mpc_set_shift", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
     "altro_mpc_prepare_async", "altro_batch_benchmark_solve", "altro_mpc_set_dynamics_track",
-    "altro_batch_get_confirm_counter",
+    "altro_batch_get_confirm_counter", "altro_batch_get_reuse_counter",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -136,6 +136,7 @@ def lib():
     L.altro_batch_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.altro_mpc_prepare_async.argtypes = [H, C.c_int32]
     L.altro_batch_get_confirm_counter.argtypes = [H, C.POINTER(C.c_int64)]
+    L.altro_batch_get_reuse_counter.argtypes = [H, C.POINTER(C.c_int64)]
     L.altro_mpc_set_dynamics_track.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32, C.c_int32]
     L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     for name in EXPORTS:

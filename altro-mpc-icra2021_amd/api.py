@@ -248,6 +248,12 @@ def set_dynamics_track(solver, A, B, d=None, step_stride=1):
     solver._chk(solver._L.altro_mpc_set_dynamics_track(solver.h, _p(Ac), _p(Bc), _p(dc), int(nblocks), int(step_stride), int(per_instance)))
 
 
+def set_tracking_cost(solver, Q, R, Qf, dt=None):
+    """Replace the diagonal weights of the tracking objective (TO.TrackingObjective(Q, R, Z; Qf), mpc.jl:26-29)."""
+    dt = solver.prob.model.dt if dt is None else dt
+    solver._chk(solver._L.altro_batch_set_tracking_cost(solver.h, _p(_c(Q)), _p(_c(R)), _p(_c(Qf)), dt))
+
+
 def set_options(solver, **kw):
     for k, v in kw.items():
         setattr(solver.opts, k, v)
@@ -400,14 +406,25 @@ def confirm_counter(solver):
     return a
 
 
+def reuse_counter(solver):
+    """iterations per instance (since timing_reset) that took their gains from memory instead of running a backward
+    pass (altro_batch_get_reuse_counter)."""
+    a = np.zeros(solver.B, dtype=np.int64)
+    solver._chk(solver._L.altro_batch_get_reuse_counter(solver.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+    return a
+
+
 def wave_cycles(solver):
-    """(waves, 8) s_memtime ticks of the last solve launch per wave: total, backward, closed
-    rollouts, open rollouts, Todorov gradient, dual update (diagnostic)."""
+    """(waves, 16) per wave of the last solve launch (16-lane kernels): s_memtime ticks in total (column 0) and, in
+    the -DALTRO_PHASE_STAMPS build, per phase: 1 four-row backward passes, 2 closed-loop rollouts, 3 open-loop rollouts,
+    4 Todorov gradient, 5 dual update, 6 line-search sweeps, 8 lone-row backward passes, 9 first-order sweeps,
+    10 costate sweeps; 11-15 how many four-row passes, first-order sweeps, costate sweeps, closed-loop rollouts and
+    trial sweeps the wave ran.  Column 7 (every build): backward passes run in the lone-row form."""
     cnt = C.c_int32(0)
     solver._chk(solver._L.altro_batch_get_wave_cycles(solver.h, None, 0, C.byref(cnt)))
     out = np.zeros(cnt.value, dtype=np.int64)
     solver._chk(solver._L.altro_batch_get_wave_cycles(solver.h, out.ctypes.data_as(C.POINTER(C.c_int64)), cnt.value, C.byref(cnt)))
-    return out.reshape(-1, 8)
+    return out.reshape(-1, 16)
 
 
 def solve_counters(solver):

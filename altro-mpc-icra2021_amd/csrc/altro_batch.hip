@@ -42,12 +42,21 @@ struct altro_handle {
   double *Gcol = nullptr, *Grow = nullptr, *fvec = nullptr;
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lb = nullptr, *mu = nullptr,
-         *KD = nullptr, *Qz = nullptr;
+         *KD = nullptr, *Qz = nullptr, *Dff = nullptr, *kmu = nullptr;
+  altro::AHash* ahash = nullptr;  // [Bp][16] active set of the backward pass behind the gains in KD (gain reuse, solve_dpp16.h)
+  long long* n_fo = nullptr;
   double *noise = nullptr, *noise_w = nullptr;
   int* noise_grp = nullptr;
   int noise_mode = 0;
   int mpc_shift = 1;
+  int reuse = 1;  // gain reuse (solve_dpp16.h fosweep); ALTRO_NO_REUSE=1 at create time switches it off (tests)
+  int lone = 1;  // backward_lone (solve_dpp16.h); ALTRO_NO_LONE=1 at create time switches it off (tests: lone == four-row pass bit for bit)
   int* cur = nullptr;
+  int *perm = nullptr, *gscore = nullptr;  // [Bp] wave slot -> instance of a grouped MPC launch, and its sort key
+  bool debug_keep_gains = false;           // ALTRO_DEBUG_KEEP_GAINS=1 at create time: the setters do NOT drop the stored gains (exists
+                                           // to show that the tests notice stale gains; never set in production)
+  int group = 1;                           // ALTRO_NO_GROUP=1 at create time: identity
+  int resync = 1;                          // ALTRO_NO_RESYNC=1 at create time: rows never wait for their wave-mates
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
   double* stage = nullptr;  // device staging buffer for host<->device layout conversion
@@ -303,6 +312,64 @@ __global__ void k_plane_copy(double* __restrict__ Zp, double* __restrict__ Zs, c
   }
 }
 
+// ---- grouping of the instances of a fused MPC launch (solve_dpp16.h: a wave executes the union of the phases its
+// four rows need, so rows with the same needs belong in the same wave).  Whether an instance will need backward
+// passes is decided by whether its window holds an active box row: then the active set moves with the window from one
+// step to the next and the gains cannot be taken from memory (47 % of the headline's instances need no pass in 20
+// steps, 40 % one at nearly every step; tools/gpu_class_persist.py).  The tracking problem follows its reference, so
+// the REFERENCE tells which windows those are: score = number of the launch's steps whose window holds a reference
+// knot at (or within 2 % of) a bound.  It is a scheduling heuristic only: results do not depend on which rows share a
+// wave (tests: instance results do not depend on the batch; lone-row == four-row pass bit for bit).
+__global__ void k_group_score(const double* __restrict__ Zref, const double* __restrict__ zmin, const double* __restrict__ zmax,
+                              int* __restrict__ score, int Bp, int first, int nsteps, int k0, int k1, int nz) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  const int W = k1 - k0 + 1;                 // knots of a window that carry the box rows
+  const int a0 = first + 1 + k0;             // first absolute knot touched by the launch's windows
+  const int na = nsteps + W - 1;             // absolute knots touched
+  unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
+  if (na > 256 || W < 1) { score[b] = 0; return; }
+  for (int a = 0; a < na; ++a) {
+    const double* z = Zref + ((size_t)(a0 + a) * Bp + b) * LW;
+    bool act = false;
+    for (int e = 0; e < nz; ++e) {
+      const double lo = zmin[e], hi = zmax[e];
+      const bool fl = lo > -1e300, fh = hi < 1e300;
+      const double m = 0.02 * ((fl && fh) ? 0.5 * (hi - lo) : fmax(1.0, fabs(fh ? hi : lo)));
+      act |= (fh && z[e] >= hi - m) || (fl && z[e] <= lo + m);
+    }
+    if (act) bits[a >> 6] |= 1ull << (a & 63);
+  }
+  int cnt = 0, sc = 0;
+  for (int a = 0; a < W; ++a) cnt += (int)((bits[a >> 6] >> (a & 63)) & 1ull);
+  for (int st = 0; st < nsteps; ++st) {
+    sc += cnt > 0 ? 1 : 0;
+    const int out = st, in = st + W;
+    cnt -= (int)((bits[out >> 6] >> (out & 63)) & 1ull);
+    if (in < na) cnt += (int)((bits[in >> 6] >> (in & 63)) & 1ull);
+  }
+  score[b] = sc;
+}
+
+// perm[rank of instance i among (score, i)] = i: a deterministic sort by counting (Bp^2 compares: microseconds)
+__global__ void k_group_rank(const int* __restrict__ score, int* __restrict__ perm, int Bp) {
+  __shared__ int tile[1024];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int si = i < Bp ? score[i] : 0;
+  int rank = 0;
+  for (int t0 = 0; t0 < Bp; t0 += 1024) {
+    for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (t0 + t < Bp) ? score[t0 + t] : 0x7fffffff;
+    __syncthreads();
+    const int tn = (Bp - t0 < 1024) ? Bp - t0 : 1024;
+    for (int t = 0; t < tn; ++t) {
+      const int sj = tile[t];
+      rank += (sj < si || (sj == si && t0 + t < i)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (i < Bp) perm[rank] = i;
+}
+
 __global__ void k_fill(double* p, double v, size_t nelem) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nelem) p[t] = v;
@@ -326,7 +393,8 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.reuse = h->reuse; p.resync = h->resync;
+  p.Dff = h->Dff; p.ahash = h->ahash; p.kmu = h->kmu; p.n_fo = h->n_fo;
   p.Qz = h->Qz;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta;
   p.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
@@ -336,6 +404,15 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
   p.n_gconf = h->n_gconf; p.dzero = h->dzero;
   p.o = h->o;
+  p.perm = nullptr;
+  // fused MPC launches of box-constrained problems: group the instances by how many of the launch's steps will need
+  // backward passes (see k_group_score); everything else runs in instance order
+  if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
+    hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
+                       first_step, nsteps, h->box_k0, h->box_k1, h->d.n + h->d.m);
+    hipLaunchKernelGGL(k_group_rank, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp);
+    p.perm = h->perm;
+  }
   const dim3 grid(h->Bp / IPW), block(64);
   const int n = h->d.n, m = h->d.m;
   const bool cones = h->ncrows > 0;
@@ -344,14 +421,30 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
     if (cones) hipLaunchKernelGGL((altro::solve_kernel<NX_, NU_, true>), grid, block, 0, h->stream, p);  \
     else hipLaunchKernelGGL((altro::solve_kernel<NX_, NU_, false>), grid, block, 0, h->stream, p);       \
   } while (0)
+#ifdef ALTRO_DEV_HEADLINE_ONLY  // development builds: only the headline instantiation (compiles in a fraction of the time)
+  if (n == 12 && m == 4 && !cones) hipLaunchKernelGGL((altro::solve_kernel<12, 4, false>), grid, block, 0, h->stream, p);
+  else FAIL(h, ALTRO_ERR_UNSUPPORTED, "development build: only (12, 4) without cones");
+#else
   if (n == 12 && m == 4) ALTRO_LAUNCH(12, 4);
   else if (n == 6 && m == 3) ALTRO_LAUNCH(6, 3);
   else if (n == 6 && m == 6) ALTRO_LAUNCH(6, 6);
   else if (n == 8 && m == 4) ALTRO_LAUNCH(8, 4);
   else if (n == 12 && m == 3) ALTRO_LAUNCH(12, 3);
   else FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
+#endif
 #undef ALTRO_LAUNCH
   HIPCHK(h, hipGetLastError());
+  return ALTRO_OK;
+}
+
+// The gains kept in KD for reuse (solve_dpp16.h fosweep) depend on the dynamics, the cost weights, the set of bounded
+// elements and the options: every setter of those drops them (kmu < 0: no valid gains).  Trajectories, duals and
+// reference windows need no such care: the active set they produce is hashed and compared at every use.
+static int drop_gains(altro_handle* h) {
+  if (h->kmu && !h->debug_keep_gains) {
+    hipLaunchKernelGGL(k_fill, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->kmu, -1.0, (size_t)h->Bp);
+    HIPCHK(h, hipGetLastError());
+  }
   return ALTRO_OK;
 }
 
@@ -473,6 +566,11 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->d = *dims;
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
+    { const char* nl = getenv("ALTRO_NO_LONE"); h->lone = (nl && nl[0] == '1') ? 0 : 1; }
+    { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
+    { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
+    { const char* ng = getenv("ALTRO_NO_GROUP"); h->group = (ng && ng[0] == '1') ? 0 : 1; }
+    { const char* nr = getenv("ALTRO_NO_REUSE"); h->reuse = (nr && nr[0] == '1') ? 0 : 1; }
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {
       g_create_err = std::string(what) + ": " + hipGetErrorString(er);
@@ -535,8 +633,17 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->mu, Bp * sizeof(double)));
     CCHK(hipMalloc(&h->KD, N * Bp * m * LW * sizeof(double)));  // N-1 gain blocks + a trash slot
     CCHK(hipMalloc(&h->Qz, (N + 1) * row * sizeof(double)));
+    CCHK(hipMalloc(&h->Dff, (N + 1) * row * sizeof(double)));
+    CCHK(hipMemsetAsync(h->Dff, 0, (N + 1) * row * sizeof(double), h->stream));
+    CCHK(hipMalloc(&h->ahash, row * sizeof(altro::AHash)));
+    CCHK(hipMemsetAsync(h->ahash, 0, row * sizeof(altro::AHash), h->stream));
+    CCHK(hipMalloc(&h->kmu, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->n_fo, Bp * sizeof(long long)));
+    CCHK(hipMemsetAsync(h->n_fo, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->Qz, 0, (N + 1) * row * sizeof(double), h->stream));
     CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->perm, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->gscore, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->iters, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->iters_outer, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->status, Bp * sizeof(int)));
@@ -548,7 +655,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemsetAsync(h->atrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
     CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
-    CCHK(hipMalloc(&h->wave_cycles, Bp * 2 * sizeof(long long)));
+    CCHK(hipMalloc(&h->wave_cycles, Bp * 4 * sizeof(long long)));
     CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
@@ -561,7 +668,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
-    CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 2 * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 4 * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
@@ -585,6 +692,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       CCHK(hipStreamSynchronize(h->stream));
     }
     hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->mu, 1.0, (size_t)Bp);
+    hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->kmu, -1.0, (size_t)Bp);  // no gains yet
     CCHK(hipStreamSynchronize(h->stream));
   #undef CCHK
     *out = h;
@@ -602,7 +710,8 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
-                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz};
+                   (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz,
+                   (void**)&h->Dff, (void**)&h->ahash, (void**)&h->kmu, (void**)&h->n_fo, (void**)&h->perm, (void**)&h->gscore};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
   h->stage_bytes = 0;
@@ -675,6 +784,7 @@ int32_t altro_batch_set_dynamics(altro_handle* h, const double* A, const double*
                        h->stage + nb * n * n, f ? h->stage + nb * (n * n + n * m) : nullptr, h->Gcol, h->Grow, h->fvec,
                        h->d.batch, h->Bp, (int)n, (int)m, per_instance ? 1 : 0);
     HIPCHK(h, hipGetLastError());
+    if (int rcd = drop_gains(h)) return rcd;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_dyn = true;
     h->dyn_per_instance = per_instance != 0;
@@ -693,6 +803,7 @@ int32_t altro_batch_set_tracking_cost(altro_handle* h, const double* Qd, const d
     for (int j = 0; j < m; ++j) wd[n + j] = dt * Rd[j];
     HIPCHK(h, hipMemcpyAsync(h->wd, wd.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->wf, wf.data(), LW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (int rcd = drop_gains(h)) return rcd;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->dt = dt;
     h->have_cost = true;
@@ -845,6 +956,7 @@ int32_t altro_batch_add_constraint(altro_handle* h, int32_t kind, int32_t sense,
       HIPCHK(h, hipMalloc(&h->Lb, lbytes));
       HIPCHK(h, hipMemsetAsync(h->Lb, 0, lbytes, h->stream));
     }
+    if (int rcd = drop_gains(h)) return rcd;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->box_k0 = k_first;
     h->box_k1 = k_last;
@@ -980,7 +1092,8 @@ int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
     if (h && h->wide && o) { h->wide->o = *o; h->wide->gains_valid = false; h->o = *o; return ALTRO_OK; }
     if (!h || !o) return ALTRO_ERR_INVALID_ARG;
     h->o = *o;
-    return ALTRO_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    return drop_gains(h);
   });
 }
 
@@ -1154,13 +1267,16 @@ int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
     // matrix: the active set was verified unchanged), its feedforward terms are zero (include/altro_batch.h, strict)
     std::vector<int> dz(Bp);
     HIPCHK(h, hipMemcpy(dz.data(), h->dzero, Bp * sizeof(int), hipMemcpyDeviceToHost));
-    // device layout [k][instance][control a][lane]: state lane j holds K[a][j], control lane n+a holds d[a]
+    std::vector<double> df((N - 1) * Bp * LW);
+    HIPCHK(h, hipMemcpy(df.data(), h->Dff, df.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // device layout KD [k][instance][control a][lane]: state lane j holds K[a][j] (the control lanes carry the factors of
+    // Quu); Dff [k][instance][lane]: control lane n+a holds d[a]
     for (size_t b = 0; b < B; ++b)
       for (size_t k = 0; k + 1 < N; ++k)
         for (size_t a = 0; a < m; ++a) {
           const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
           if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
-          if (d) d[(b * (N - 1) + k) * m + a] = dz[b] ? 0.0 : row[n + a];
+          if (d) d[(b * (N - 1) + k) * m + a] = dz[b] ? 0.0 : df[(k * Bp + b) * LW + n + a];
         }
     return ALTRO_OK;
   });
@@ -1192,6 +1308,7 @@ int32_t altro_batch_timing_reset(altro_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->n_ok, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->n_trials, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->n_gconf, 0, h->Bp * sizeof(long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->n_fo, 0, h->Bp * sizeof(long long), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ALTRO_OK;
   });
@@ -1238,6 +1355,21 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
   });
 }
 
+int32_t altro_batch_get_reuse_counter(altro_handle* h, int64_t* reused) {
+  return guard(h, [&]() -> int32_t {
+    if (!h || !reused) return ALTRO_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->wide) {
+      HIPCHK(h, hipStreamSynchronize(h->wide->stream));
+      HIPCHK(h, hipMemcpy(reused, h->wide->n_gs, (size_t)h->d.batch * sizeof(long long), hipMemcpyDeviceToHost));
+      return ALTRO_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(reused, h->n_fo, (size_t)h->d.batch * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
+}
+
 int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed) {
   return guard(h, [&]() -> int32_t {
     if (!h || !confirmed) return ALTRO_ERR_INVALID_ARG;
@@ -1260,7 +1392,7 @@ int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t ca
     if (!h || !count) return ALTRO_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int32_t n = h->Bp / IPW * 8;
+    const int32_t n = h->Bp / IPW * 16;
     *count = n;
     if (cycles) HIPCHK(h, hipMemcpy(cycles, h->wave_cycles, (size_t)(n < capacity ? n : capacity) * sizeof(long long), hipMemcpyDeviceToHost));
     return ALTRO_OK;

@@ -117,6 +117,36 @@ def gen(NX, NU):
         [(f"h{i}", f"h[{i}]") for i in range(NZ)],
         [(f"c{r}", f"acol[{r}]") for r in range(16)] + [(f"y{r}", f"y[{r}]") for r in range(16)]))
 
+
+    # ---- lone-row blocks: ONE instance spread over the wave's four DPP rows (solve_dpp16.h backward_lone).
+    # Row r of the wave owns rows i = r*RL + t (t < RL) of S, W and Qxx, row 0 also the vector s (slot RL), and the
+    # rows NX + r*RQ + u (u < RQ) of [Qux Quu]; every row holds all 16 columns (lane j = column j as before).
+    # Every output element is the same chain of FMAs in the same order as in SG / GtW / CTG0, so the lone pass
+    # is bit-identical to the four-row pass.
+    RL = (NX + 3) // 4
+    RQ = (NU + 3) // 4
+    out.append(f"  static constexpr int RL = {RL}, RQ = {RQ};\n")
+    # SGL: w[t] += sum_k bcast_k(Sl[t]) * g[k],  t <= RL
+    body = [fmac(f"w{t}", f"s{t}", f"g{k}", k) for k in range(NX) for t in range(RL + 1)]
+    out.append(emit_block(
+        "SGL", f"double (&w)[{RL + 1}], const double (&Sl)[{RL + 1}], const double (&g)[{NX}]", body,
+        [(f"w{t}", f"w[{t}]") for t in range(RL + 1)],
+        [(f"s{t}", f"Sl[{t}]") for t in range(RL + 1)] + [(f"g{k}", f"g[{k}]") for k in range(NX)]))
+    # GTWL: h[t] += sum_k bcast_t(gp[k]) * wa[k],  t < RL + RQ  (gp: the row's own columns of G, permuted to lanes 0..)
+    body = [fmac(f"h{t}", f"g{k}", f"w{k}", t) for k in range(NX) for t in range(RL + RQ)]
+    out.append(emit_block(
+        "GTWL", f"double (&h)[{RL + RQ}], const double (&gp)[{NX}], const double (&wa)[{NX + 1}]", body,
+        [(f"h{t}", f"h[{t}]") for t in range(RL + RQ)],
+        [(f"g{k}", f"gp[{k}]") for k in range(NX)] + [(f"w{k}", f"wa[{k}]") for k in range(NX)]))
+    # CTGL0: h[t] += sum_a bcast_t(rp[a]) * kd[a],  t < RL  (rp: Qux rows permuted like gp)
+    body = []
+    for a in range(NU):
+        body += [fmac(f"h{t}", f"r{a}", f"k{a}", t) for t in range(RL)]
+    out.append(emit_block(
+        "CTGL0", f"double (&h)[{RL + RQ}], const double (&kd)[{NU}], const double (&rp)[{NU}]",
+        body, [(f"h{t}", f"h[{t}]") for t in range(RL)],
+        [(f"k{a}", f"kd[{a}]") for a in range(NU)] + [(f"r{a}", f"rp[{a}]") for a in range(NU)]))
+
     out.append("};\n\n")
     return "".join(out)
 

@@ -85,6 +85,12 @@ namespace altro {
 constexpr int LW = 16;  // lanes per instance (one DPP row)
 constexpr int IPW = 4;  // instances per wave
 
+// Active-set hash of one lane (see Solver::hash_add)
+struct AHash {
+  unsigned a, b;
+};
+__device__ __forceinline__ bool operator!=(const AHash& x, const AHash& y) { return (x.a != y.a) | (x.b != y.b); }
+
 struct SolveParams {
   int B, Bp, N;
   int kref;              // first knot of the reference window inside Zref (plain solve)
@@ -109,11 +115,15 @@ struct SolveParams {
   int mpc_shift;         // 1: shift_fill primal + dual at every MPC step (default); 0: keep (flexible_sat_mpc.jl:275-276)
   double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
   int* cur;              // [Bp] which plane of Z is current
+  const int* perm;       // [Bp] wave slot -> instance (grouped MPC launches: altro_batch.hip k_group_score); null: identity
   double* Lb;            // [N+1][Bp][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
                          // z - zmax <= 0, side 1 = duals of zmin - z <= 0  (knot N = trash row)
   const int* bslot;      // [16] slot of lane j's element among the bounded ones, -1 if unbounded
   int nbp;               // slots per side (>= 1)
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
+  int resync;            // 1: rows wait a turn to stay in step with their wave-mates (run(), phase A)
+  int reuse;             // 1: gain reuse (fosweep) allowed; ALTRO_NO_REUSE=1 at create time switches it off
+  int lone;              // 1: a backward pass that only one row of a wave needs runs spread over the four DPP rows (backward_lone)
   // generic affine constraints (LINEAR eq/ineq, SOC): up to 16 constraint rows per knot, row r
   // on lane r, organised in 4 quads of 4 lanes; a quad is one cone (SOC of dimension <= 4, or
   // up to 4 independent equality / inequality rows).  Data is shared by all instances.
@@ -129,7 +139,12 @@ struct SolveParams {
   int ncrows;            // 0: no generic constraints
   double* Qz;            // [N+1][Bp][16] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced
                          // (l_x on the state lanes, l_u on the control lanes; knot N = trash): input of the costate sweep
-  double* KD;            // [N][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes, d[a] in lanes >= NX; block N-1 = trash
+  double* KD;            // [N][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes; lane NX + b (b <= a) holds entry (a, b) of
+                         // the factors of Quu = L D L' (1 / D_a on the diagonal, L below it); block N-1 = trash
+  double* Dff;           // [N+1][Bp][16] feedforward terms: d[a] on lane NX + a (knot N = trash)
+  AHash* ahash;          // [Bp][16] per lane: active set of the backward pass that left the gains in KD (kept between launches)
+  double* kmu;           // [Bp] penalty of that pass; < 0: the gains in KD must not be reused
+  long long* n_fo;       // [Bp] iterations that took their gains from memory (first-order sweep instead of a backward pass)
   int* iters;
   int* iters_outer;
   int* status;
@@ -146,7 +161,7 @@ struct SolveParams {
   long long* n_ok;       // [Bp] solves that ended SOLVE_SUCCEEDED
   long long* n_gconf;    // [Bp] iterations confirmed by the costate sweep instead of a backward pass
   int* dzero;            // [Bp] 1: the feedforward terms of the last solve's last iteration are zero (costate-confirmed)
-  long long* wave_cycles; // [Bp/4][8] shader cycles of the last launch, per wave (diagnostic):
+  long long* wave_cycles; // [Bp/4][16] shader cycles of the last launch, per wave (diagnostic):
                           // total, backward, closed rollouts, open rollouts, todorov, dual update,
                           // streaming line-search sweeps
   altro_opts o;
@@ -352,10 +367,14 @@ struct RowState {
   double J, cmax, J_prev, rho, drho, mu, dV1, dV2, cost_tol, grad_tol;
   int phase, status, iters, iters_outer, outer, it, dj_zero, cur, kref, step, shift, last;
   int nbw, nro, nsolve, nit, nok, ntr;
-  int bw_plain;   // the gains in KD come from a backward pass of THIS inner solve that ran with rho == 0
+  double kmu;     // penalty of the backward pass (rho == 0, every pivot positive) that left the gains in KD; < 0: none
   int qvalid;     // Qz (and the hash in qhash) describe the CURRENT trajectory: its last step was an accepted alpha = 1 rollout
   int gconf;      // the last iteration of the last solve was confirmed by the costate sweep (its d is exactly 0)
   int ngc;        // iterations confirmed by the costate sweep (work counter)
+  int nfo;        // iterations that took their gains from memory (work counter)
+#ifdef ALTRO_DIAG_REUSE
+  double bwmu;
+#endif
 };
 
 template <int NX, int NU, bool CONES>
@@ -368,27 +387,33 @@ struct Solver {
   double* sm;    // this row's 16 x 17 transpose tile (LDS)
   bool hard_wave = false;  // wave-uniform: a row of this wave is in a hard solve (see ALTRO_PRIO_HARD)
   int turns = 0;           // turns of the wave loop so far
-  unsigned* ah;  // this lane's active-set hash of the last backward pass (LDS)
-  unsigned* qhs; // this lane's active-set hash of the trajectory in Qz (LDS)
+  int n_lone = 0;          // backward passes of this launch that ran as backward_lone (diagnostic, wave_cycles[7])
+#ifdef ALTRO_DIAG_REUSE
+  int d_same0 = 0, d_same1 = 0, d_all0 = 0, d_all1 = 0;  // passes whose active set and penalty equal the row's previous pass (first / later iteration)
+#endif
+  AHash* ah;   // this lane's active-set hash of the backward pass that left the gains in KD (LDS; kept in P.ahash between launches)
+  AHash* qhs;  // this lane's active-set hash of the trajectory in Qz (LDS)
   int lane, j, inst;
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
   unsigned kstride;  // Bp*16                 that every array stays below 2^32 bytes)
   unsigned lslot;    // this lane's slot in the compact dual rows (0 for unbounded lanes: dummy)
   bool bounded;
-  ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls;)
+  ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls; long long t_fo; long long t_aj; long long t_bl;
+              long long c_bw; long long c_fo; long long c_aj; long long c_rc; long long c_ls;)
 
   struct LaneConst {
     double wd, wf, zmin, zmax;
     bool has_hi, has_lo;
   };
 
-  __device__ Solver(const SolveParams& p, RowState* rows, double* tiles, unsigned* hashes) : P(p) {
+  __device__ Solver(const SolveParams& p, RowState* rows, double* tiles, AHash* hashes) : P(p) {
     lane = threadIdx.x & 63;
     ah = hashes + (threadIdx.x & 63);
     qhs = hashes + 64 + (threadIdx.x & 63);
     j = lane & 15;
     inst = blockIdx.x * IPW + (lane >> 4);
+    if (P.perm != nullptr) inst = P.perm[inst];
     rs = rows + (lane >> 4);
     sm = tiles + (lane >> 4) * (LW * (LW + 1));
     is_x = j < NX;
@@ -400,7 +425,7 @@ struct Solver {
       bounded = sl >= 0;
       lslot = bounded ? (unsigned)sl : 0u;
     }
-    ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = 0;)
+    ALTRO_STAMP(t_bw = t_rc = t_ro = t_td = t_du = t_ls = t_fo = t_aj = t_bl = c_bw = c_fo = c_aj = c_rc = c_ls = 0;)
   }
 
   // ---- generic constraint rows (CONES): this lane owns constraint row j of every knot
@@ -486,9 +511,15 @@ struct Solver {
 
   // Active-set hash of one lane: a position-weighted sum of the 2-bit codes, so that the backward pass (knots in
   // descending order) and the rollout (ascending) arrive at the same number for the same active set.
-  static __device__ __forceinline__ unsigned hash_add(unsigned h, unsigned code, int k) {
-    const unsigned mk = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;   // 24 bits: v_mad_u32_u24 runs at full rate
-    return __umul24(code, mk) + h;
+  // Two independent 32-bit sums (64 bits per lane): the hash of the gains in memory is compared with the active sets of
+  // unrelated later solves, launch after launch (gain reuse), so a collision must be out of reach, not just unlikely
+  // within one solve.
+  static __device__ __forceinline__ AHash hash_add(AHash h, unsigned code, int k) {
+    const unsigned ka = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;   // 24 bits: v_mad_u32_u24 runs at full rate
+    const unsigned kb = (((unsigned)(2 * k + 1)) * 2246822519u) >> 8;
+    h.a += __umul24(code, ka);
+    h.b += __umul24(code, kb);
+    return h;
   }
 
   // max over the NU control lanes of this row
@@ -538,12 +569,13 @@ struct Solver {
     bool limit;
     bool unchanged;  // the trial reproduced plane `cur` bit for bit (closed-loop rollouts only)
     bool tiny;       // every element moved by at most 1e-7 (1 + |z|)            (closed-loop rollouts only)
-    unsigned qh;     // per lane: hash of the active set at the trajectory produced (closed-loop rollouts only)
+    AHash qh;        // per lane: hash of the active set at the trajectory produced (box-only kernels)
   };
 
   struct KnotIn {
     double z, zr, lhi, llo;
-    double kcol[NU <= 4 ? 4 : NU];  // closed loop: x lane j holds K[:, j]; u lane NX+a holds d[a] (slot order: see rollout)
+    double kcol[NU <= 4 ? 4 : NU];  // closed loop: x lane j holds K[:, j] (slot order: see rollout)
+    double dff;                     // closed loop: u lane NX + a holds d[a]
     double lc, lcn;   // dual of this lane's constraint row at the knot and at the next one (CONES)
   };
 
@@ -579,7 +611,7 @@ struct Solver {
     double xb = ldg(P.x0, rowoff);
     double Jacc = 0.0, viol = 0.0;
     bool limit = false, changed = false, big = false;
-    unsigned qh = 0u;
+    AHash qh = {0u, 0u};
     const int k1 = P.box_k1;
     const bool shl = OPEN && shift;           // per row
     const bool shu = shl && !is_x;            // controls are read one knot ahead
@@ -620,6 +652,7 @@ struct Solver {
         } else {
           sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
         }
+        in.dff = ldg(P.Dff, at(k));
       }
       in.lc = 0.0;
       in.lcn = 0.0;
@@ -646,7 +679,8 @@ struct Solver {
       } else {
         // du = K dx: x lane j contributes K[:, j] dx_j; the NX-lane sums run as DPP FMAs
         const double dx = is_x ? (xb - in.z) : 0.0;
-        double du, dff = in.kcol[0];
+        double du;
+        const double dff = in.dff;
         if constexpr (NU <= 4) {
           // four row sums over the x lanes in 15 VALU: lanes trade two slots with lane^1, one with
           // lane^2 (afterwards every lane of a quad holds the quad's part of row (l&3)-NX), then the
@@ -673,7 +707,6 @@ struct Solver {
             constexpr int A = decltype(a)::value;
             const double da = (acc[A][0] + acc[A][1]) + acc[A][2];
             du = (j == NX + A) ? da : du;
-            dff = (j == NX + A) ? in.kcol[A] : dff;
           });
         }
         const double ub = in.z + du + dff;  // alpha = 1
@@ -682,7 +715,7 @@ struct Solver {
         big = big | ((is_x | is_u) & !(fabs(zb - in.z) <= 1e-7 * (1.0 + fabs(in.z))));
         stg(P.Z, zd + at(k), zb);
       }
-      if constexpr (!OPEN && !CONES) {
+      if constexpr (!CONES) {
         double qz;
         unsigned code;
         Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol, qz, code);
@@ -749,7 +782,7 @@ struct Solver {
       const double zb = is_x ? xb : 0.0;
       if constexpr (OPEN) stg(P.Z, at(take ? cur * N + kt : 2 * N), zb);
       else stg(P.Z, zd + at(kt), zb);
-      if constexpr (!OPEN && !CONES) {
+      if constexpr (!CONES) {
         double qz;
         unsigned code;
         Jacc += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
@@ -789,7 +822,6 @@ struct Solver {
     prio_serial();
     const unsigned zs = plane(rs->cur);
     const int N = P.N;
-    const int ra = is_u ? (j - NX) : 0;
     double acc = 0.0;
     constexpr int UN = ALTRO_UN;
     const int nch = (N - 1 + UN - 1) / UN;
@@ -800,7 +832,7 @@ struct Solver {
         constexpr int Tt = decltype(t)::value;
         const int k = imin(k0 + Tt, N - 2);
         u[Tt] = ldg(P.Z, zs + at(k));
-        d[Tt] = ldg(P.KD, kd_at(k, ra));
+        d[Tt] = ldg(P.Dff, at(k));
       });
       sfor<0, UN>([&](auto t) {
         constexpr int Tt = decltype(t)::value;
@@ -1006,7 +1038,7 @@ struct Solver {
       Blk<NX, NU>::HC(hh, acol, y);
     };
     // terminal expansion: S = Qf (+ box / cone hessian), s = Qf (x - xr) (+ box / cone gradient)
-    unsigned hash = 0u;  // of the active set this pass sees, knot by knot (compared by adjoint())
+    AHash hash = {0u, 0u};  // of the active set this pass sees, knot by knot
     double Sx[NX + 1];
     {
       const int k = N - 1;
@@ -1016,7 +1048,7 @@ struct Solver {
       double qz = lc.wf * (z - zr), hz = lc.wf;
       unsigned codeT;
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
-      hash = hash_add(0u, codeT, k);
+      hash = hash_add(hash, codeT, k);
       if constexpr (CONES) {
         double hT[NZ];
         sfor<0, NZ>([&](auto c) {
@@ -1160,11 +1192,7 @@ struct Solver {
       if constexpr (RHO) snew -= rho * ktd;
       dV1 += t1;
       dV2 += RHO ? (-0.5 * t1 - 0.5 * rho * dtd) : (-0.5 * t1);
-      // gains out, every lane stores its own column: x lanes K[a][j], lanes >= NX d[a]
-      sfor<0, NU>([&](auto a) {
-        constexpr int A = decltype(a)::value;
-        stg(P.KD, kd_at(live ? k : N - 1, A), is_x ? kd[A] : dd_[A]);  // knot N-1 is the trash slot
-      });
+      store_gains(live ? k : N - 1, live ? k : N, kd, L, dinv);
       // S = Qxx + Qux'K - rho K'K   (in place on h[0..NX-1]), then S = (S + S')/2
       if constexpr (RHO) {
         double T[NU];
@@ -1200,7 +1228,380 @@ struct Solver {
       lcc = lcn;
     }
     dtiny = !row_any(dbig, lane);
+#ifdef ALTRO_DIAG_REUSE
+    {
+      const bool same = !row_any(hash != *ah, lane) && (rs->bwmu == mu) && !RHO;
+      const bool first = rs->it == 0;
+      d_same0 += __popcll(__ballot(live && same && first && j == 0));
+      d_same1 += __popcll(__ballot(live && same && !first && j == 0));
+      d_all0 += __popcll(__ballot(live && first && j == 0));
+      d_all1 += __popcll(__ballot(live && !first && j == 0));
+      if (live) rs->bwmu = RHO ? -1.0 : mu;
+    }
+#endif
     if (live) *ah = hash;
+  }
+
+  // Gains of one knot out (kk / kf: the knot, or the trash slots N-1 of KD and N of Dff for rows that sit the pass out).
+  // Every lane stores its own column: x lane j the K[a][j]; u lane NX + b the factors of Quu the first-order sweep
+  // needs to get d from Qu without a backward pass -- entry (a, b) of [1 / D on the diagonal, L below] in gain row a --
+  // and, in Dff, lane NX + a the feedforward term d[a] (on the u lanes kd[] is the solve of Qu, i.e. d).
+  __device__ __forceinline__ void store_gains(int kk, int kf, const double (&kd)[NU], const double (&L)[NU][NU],
+                                              const double (&dinv)[NU]) const {
+    double dl = kd[0];
+    sfor<1, NU>([&](auto a) {
+      constexpr int A = decltype(a)::value;
+      dl = (j == NX + A) ? kd[A] : dl;
+    });
+    stg(P.Dff, at(kf), dl);
+    sfor<0, NU>([&](auto a) {
+      constexpr int A = decltype(a)::value;
+      double v = kd[A];
+      sfor<0, A>([&](auto b) {
+        constexpr int Bq = decltype(b)::value;
+        v = (j == NX + Bq) ? L[A][Bq] : v;
+      });
+      v = (j == NX + A) ? dinv[A] : v;
+      stg(P.KD, kd_at(kk, A), v);
+    });
+  }
+
+  // First-order sweep (default mode, box-only problems): an iteration whose active set and penalty are those of the
+  // backward pass that left the gains in KD -- in this solve or in an earlier one, in this launch or an earlier one --
+  // does not need that pass again.  Inside a fixed active set the AL problem is LQ: K_k and Quu_k depend on the
+  // dynamics, the weights, the penalty and WHICH rows are active, not on the trajectory, so they are what the pass
+  // would recompute.  What does depend on the trajectory is first order:
+  //     [Qx; Qu] = l_z + [A B]' s_{k+1},   d_k = -Quu^-1 Qu  (factors stored with the gains),   s_k = Qx + K_k' Qu,
+  //     dV += (d'Qu, -1/2 d'Qu)
+  // (identities of backward() with rho = 0).  l_z at the current trajectory was left in the plane Qz by the rollout that
+  // produced it.  One 12-FMA product per knot on the critical path (s_{k+1} -> s_k); the solve for d hangs off it.
+  // Writes d into Dff (rows with live), returns dV and the tiny-feedforward flag of backward().  54 % of the backward
+  // passes of the headline workload are of this kind (tools/gpu_reuse_diag.py).
+  __device__ void fosweep(bool live, double& dV1, double& dV2, bool& dtiny) {
+    phase_begin();
+    prio_serial();
+    double g[NX];
+    sfor<0, NX>([&](auto c) {
+      constexpr int C = decltype(c)::value;
+      g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
+    });
+    const unsigned zs = plane(rs->cur);
+    const int N = P.N;
+    bool dbig = false;
+    dV1 = 0.0;
+    dV2 = 0.0;
+    double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
+    constexpr int PD = 4;
+    struct In {
+      double qz, z, kr[NU];
+    };
+    In ring[PD];
+    auto load = [&](int k, In& in) {
+      in.qz = ldg(P.Qz, at(k));
+      in.z = ldg(P.Z, zs + at(k));
+      sfor<0, NU>([&](auto a) { in.kr[decltype(a)::value] = ldg(P.KD, kd_at(k, decltype(a)::value)); });
+    };
+    sfor<0, PD>([&](auto u) { load(imax(N - 2 - decltype(u)::value, 0), ring[decltype(u)::value]); });
+    const int ngroups = (N - 1 + PD - 1) / PD;
+    int k = N - 2;
+    for (int gq = 0; gq < ngroups; ++gq, k -= PD) {  // body: one basic block
+      sfor<0, PD>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        const In& in = ring[U];
+        const bool valid = k - U >= 0;
+        double acc4[4] = {in.qz, 0.0, 0.0, 0.0};
+        Blk<NX, NU>::GTS(acc4, sv, g);
+        const double gz = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);  // x lanes: Qx, u lanes: Qu
+        double qu[NU];
+        sfor<0, NU>([&](auto a) { qu[decltype(a)::value] = bcast<NX + decltype(a)::value>(gz); });
+        // s_k = Qx + K' Qu (x lanes: kr[a] = K[a][j])
+        double snew = gz;
+        sfor<0, NU>([&](auto a) { snew += in.kr[decltype(a)::value] * qu[decltype(a)::value]; });
+        // d = -(L D L')^-1 Qu, the factors from the u lanes of the gain rows (same arithmetic as backward())
+        double y[NU], dk[NU];
+        sfor<0, NU>([&](auto ii) {
+          constexpr int I = decltype(ii)::value;
+          double v = qu[I];
+          sfor<0, I>([&](auto kk) {
+            constexpr int Kk = decltype(kk)::value;
+            v -= bcast<NX + Kk>(in.kr[I]) * y[Kk];
+          });
+          y[I] = v;
+        });
+        sfor<0, NU>([&](auto ir) {
+          constexpr int I = NU - 1 - decltype(ir)::value;
+          double v = y[I] * bcast<NX + I>(in.kr[I]);
+          sfor<I + 1, NU>([&](auto kk) {
+            constexpr int Kk = decltype(kk)::value;
+            v -= bcast<NX + I>(in.kr[Kk]) * dk[Kk];
+          });
+          dk[I] = v;
+        });
+        double t1 = 0.0, dm = 0.0, dl = 0.0;
+        sfor<0, NU>([&](auto a) {
+          constexpr int A = decltype(a)::value;
+          dk[A] = -dk[A];
+          t1 += dk[A] * qu[A];
+          dm = fmax(dm, fabs(dk[A]));
+          dl = (j == NX + A) ? dk[A] : dl;
+        });
+        dbig = dbig | (valid & is_u & !(dm <= 1e-9 * (1.0 + fabs(in.z))));
+        dV1 += valid ? t1 : 0.0;
+        dV2 += valid ? -0.5 * t1 : 0.0;
+        stg(P.Dff, at((live & valid) ? k - U : N), dl);
+        sv = valid ? (is_x ? snew : 0.0) : sv;
+        load(imax(k - U - PD, 0), ring[U]);
+      });
+    }
+    dtiny = !row_any(dbig, lane);
+    prio_base();
+  }
+
+  // ---- lone-row backward pass ---------------------------------------------------------------------------
+  // When exactly one row of the wave needs a backward pass (the tail of a launch, where single hard instances walk
+  // their serial chains, and every turn of a wave whose rows are out of step), the wave's other three DPP rows
+  // would execute the pass's 396 FMAs per knot on operands nobody reads.  backward_lone() spreads the ONE instance
+  // over all four rows instead: row r owns rows r*RL .. r*RL + RL-1 of S, W = S [A B] and Qxx (row 0 also the
+  // vector s), and rows NX + r*RQ.. of [Qux Quu]; lane j is column j in every row, as before.  The rows trade their
+  // slices of W and of [Qux Quu] with v_permlane32_swap / v_permlane16_swap (gfx950), everything that is not a
+  // product (box expansion, L D L', gain solves, dV) runs redundantly on all four.  153 product / exchange
+  // instructions per knot instead of 396.  Every output element is the same chain of FMAs in the same order as in
+  // backward<false, SYM>, so the two passes agree bit for bit (tests: ALTRO_NO_LONE=1 against the default).
+  // The caller points inst / rowoff / rs / ah of ALL lanes at the lone row before the call.  rho == 0 only.
+  static __device__ __forceinline__ void rows_gather(double v, double (&o)[4]) {
+    // o[q] = v of the same lane of DPP row q
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);  // [0] = rows 0,1 | 0,1   [1] = rows 2,3 | 2,3
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const auto a0 = __builtin_amdgcn_permlane16_swap(a[0], a[0], false, false);  // [0] = row 0 everywhere, [1] = row 1
+    const auto b0 = __builtin_amdgcn_permlane16_swap(b[0], b[0], false, false);
+    const auto a1 = __builtin_amdgcn_permlane16_swap(a[1], a[1], false, false);  // [0] = row 2, [1] = row 3
+    const auto b1 = __builtin_amdgcn_permlane16_swap(b[1], b[1], false, false);
+    o[0] = __hiloint2double(b0[0], a0[0]);
+    o[1] = __hiloint2double(b0[1], a0[1]);
+    o[2] = __hiloint2double(b1[0], a1[0]);
+    o[3] = __hiloint2double(b1[1], a1[1]);
+  }
+  static __device__ __forceinline__ double rows_gather0(double v) {  // v of the same lane of DPP row 0
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const auto a0 = __builtin_amdgcn_permlane16_swap(a[0], a[0], false, false);
+    const auto b0 = __builtin_amdgcn_permlane16_swap(b[0], b[0], false, false);
+    return __hiloint2double(b0[0], a0[0]);
+  }
+  static __device__ __forceinline__ double lane_gather(double v, int src_lane) {  // v of lane src_lane (ds_bpermute)
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+
+  template <bool SYM>
+  __device__ void backward_lone(double& dV1, double& dV2, bool& fail, bool& dtiny) {
+    using BK = Blk<NX, NU>;
+    constexpr int RL = BK::RL, RQ = BK::RQ;
+    phase_begin();
+    const int rr = lane >> 4;  // the quarter of the instance this DPP row owns
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const int kref = rs->kref;
+    const unsigned zs = plane(rs->cur);
+    // g: [A B] by columns as in backward(); gp: the columns this row's own output rows need as broadcast operands,
+    // moved to lanes 0..: lane t < RL holds column rr*RL + t, lane RL + u holds control column NX + rr*RQ + u
+    double g[NX], gp[NX];
+    {
+      const int pc = (j < RL) ? rr * RL + j : NX + rr * RQ + (j - RL);
+      const bool pv = (j < RL) ? (rr * RL + j < NX) : ((j - RL < RQ) && (rr * RQ + (j - RL) < NU));
+      sfor<0, NX>([&](auto c) {
+        constexpr int C = decltype(c)::value;
+        g[C] = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + j);
+        const double v = ldg(P.Gcol, ((unsigned)inst * NX + C) * LW + (pv ? pc : 0));
+        gp[C] = pv ? v : 0.0;
+      });
+    }
+    const int N = P.N;
+    // which global row of S / Qxx a local slot of this DPP row holds, and whether this lane is its diagonal
+    bool diag_x[RL], own_x[RL], diag_u[RQ];
+    sfor<0, RL>([&](auto t) {
+      constexpr int Tt = decltype(t)::value;
+      own_x[Tt] = rr * RL + Tt < NX;
+      diag_x[Tt] = own_x[Tt] & (j == rr * RL + Tt);
+    });
+    sfor<0, RQ>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      diag_u[U] = (rr * RQ + U < NU) & (j == NX + rr * RQ + U);
+    });
+    const int psrc = (lane & 48) + ((rr * RL + j) & 15);  // lane whose [Qux] entry slot j of this row's S rows needs
+    AHash hash = {0u, 0u};
+    double Sl[RL + 1];
+    {
+      const int k = N - 1;
+      const double z = ldg(P.Z, zs + at(k));
+      const double zr = ldg(P.Zref, at(kref + k));
+      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
+      double qz = lc.wf * (z - zr), hz = lc.wf;
+      unsigned codeT;
+      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
+      hash = hash_add(hash, codeT, k);
+      sfor<0, RL>([&](auto t) { Sl[decltype(t)::value] = diag_x[decltype(t)::value] ? hz : 0.0; });
+      Sl[RL] = (is_x & (rr == 0)) ? qz : 0.0;
+    }
+    dV1 = 0.0;
+    dV2 = 0.0;
+    fail = false;
+    bool dbig = false;
+    double* my = sm;
+    double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
+    double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
+    for (int k = N - 2; k >= 0; --k) {  // body: one basic block
+      const int km = imax(k - 1, 0);
+      const double zn = ldg(P.Z, zs + at(km));
+      const double zrn = ldg(P.Zref, at(kref + km));
+      const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
+      double qz = lc.wd * (z - zr), hz = lc.wd;
+      unsigned code;
+      box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
+      hash = hash_add(hash, code, k);
+      // this row's rows of W = [S; s'] G
+      double wl[RL + 1];
+      sfor<0, RL + 1>([&](auto t) { wl[decltype(t)::value] = 0.0; });
+      BK::SGL(wl, Sl, g);
+      // all rows of W to every DPP row
+      double wa[NX + 1];
+      sfor<0, RL>([&](auto t) {
+        constexpr int Tt = decltype(t)::value;
+        double o[4];
+        rows_gather(wl[Tt], o);
+        sfor<0, 4>([&](auto q) {
+          constexpr int Q = decltype(q)::value;
+          if constexpr (Q * RL + Tt < NX) wa[Q * RL + Tt] = o[Q];
+        });
+      });
+      wa[NX] = rows_gather0(wl[RL]);
+      // this row's rows of H = G' W + diag(lzz): RL rows of Qxx, RQ rows of [Qux Quu]
+      double hl[RL + RQ];
+      sfor<0, RL>([&](auto t) { hl[decltype(t)::value] = diag_x[decltype(t)::value] ? hz : 0.0; });
+      sfor<0, RQ>([&](auto u) { hl[RL + decltype(u)::value] = diag_u[decltype(u)::value] ? hz : 0.0; });
+      BK::GTWL(hl, gp, wa);
+      const double gz = qz + wa[NX];  // Qx[j] on x lanes, Qu[a] on u lanes
+      // rows of [Qux Quu] to every DPP row: hq[a] = what backward() calls h[NX + a]
+      double hq[NU];
+      sfor<0, RQ>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        double o[4];
+        rows_gather(hl[RL + U], o);
+        sfor<0, 4>([&](auto q) {
+          constexpr int Q = decltype(q)::value;
+          if constexpr (Q * RQ + U < NU) hq[Q * RQ + U] = o[Q];
+        });
+      });
+      // the broadcast operand of S = Qxx + Qux'K on this row's rows: Qux[a][i] of row i = rr*RL + t sits on lane i
+      // (requested here: the ds_bpermute round trip hides behind the factorisation)
+      double rp[NU];
+      sfor<0, NU>([&](auto a) { rp[decltype(a)::value] = lane_gather(hq[decltype(a)::value], psrc); });
+      double quu[NU][NU];
+      double qu[NU];
+      sfor<0, NU>([&](auto a) {
+        constexpr int A = decltype(a)::value;
+        qu[A] = bcast<NX + A>(gz);
+        sfor<0, A + 1>([&](auto b) {
+          constexpr int Bq = decltype(b)::value;
+          quu[A][Bq] = bcast<NX + Bq>(hq[A]);
+        });
+      });
+      double L[NU][NU], Ld[NU][NU], dinv[NU];
+      sfor<0, NU>([&](auto jc) {
+        constexpr int Jc = decltype(jc)::value;
+        double dd = quu[Jc][Jc];
+        sfor<0, Jc>([&](auto kk) {
+          constexpr int Kk = decltype(kk)::value;
+          dd -= L[Jc][Kk] * Ld[Jc][Kk];
+        });
+        fail = fail | !(dd > 0.0);
+        dinv[Jc] = rcp_nr(dd);
+        sfor<Jc + 1, NU>([&](auto ii) {
+          constexpr int I = decltype(ii)::value;
+          double v = quu[I][Jc];
+          sfor<0, Jc>([&](auto kk) {
+            constexpr int Kk = decltype(kk)::value;
+            v -= L[I][Kk] * Ld[Jc][Kk];
+          });
+          Ld[I][Jc] = v;
+          L[I][Jc] = v * dinv[Jc];
+        });
+      });
+      double r[NU], kd[NU];
+      sfor<0, NU>([&](auto a) {
+        constexpr int A = decltype(a)::value;
+        r[A] = is_x ? hq[A] : qu[A];
+      });
+      {
+        double y[NU];
+        sfor<0, NU>([&](auto ii) {
+          constexpr int I = decltype(ii)::value;
+          double v = r[I];
+          sfor<0, I>([&](auto kk) { v -= L[I][decltype(kk)::value] * y[decltype(kk)::value]; });
+          y[I] = v;
+        });
+        sfor<0, NU>([&](auto ir) {
+          constexpr int I = NU - 1 - decltype(ir)::value;
+          double v = y[I] * dinv[I];
+          sfor<I + 1, NU>([&](auto kk) { v -= L[decltype(kk)::value][I] * kd[decltype(kk)::value]; });
+          kd[I] = v;
+        });
+        sfor<0, NU>([&](auto a) { kd[decltype(a)::value] = -kd[decltype(a)::value]; });
+      }
+      {
+        double dm = fabs(kd[0]);
+        sfor<1, NU>([&](auto a) { dm = fmax(dm, fabs(kd[decltype(a)::value])); });
+        dbig = dbig | (is_u & !(dm <= 1e-9 * (1.0 + fabs(z))));
+      }
+      double dd_[NU];
+      sfor<0, NU>([&](auto a) { dd_[decltype(a)::value] = bcast<NX>(kd[decltype(a)::value]); });
+      double snew = gz, t1 = 0.0;
+      sfor<0, NU>([&](auto a) {
+        constexpr int A = decltype(a)::value;
+        snew += r[A] * dd_[A];
+        t1 += dd_[A] * qu[A];
+      });
+      dV1 += t1;
+      dV2 += -0.5 * t1;
+      store_gains((rr == 0) ? k : N - 1, (rr == 0) ? k : N, kd, L, dinv);  // one row stores; the others hit the trash slots
+      BK::CTGL0(hl, kd, rp);  // S = Qxx + Qux'K on this row's rows
+      if constexpr (SYM) {
+        sfor<0, RL>([&](auto t) {
+          constexpr int Tt = decltype(t)::value;
+          my[(rr * RL + Tt) * (LW + 1) + j] = hl[Tt];  // rows >= NX of the tile are never read by a state lane
+        });
+        __builtin_amdgcn_wave_barrier();
+        sfor<0, RL>([&](auto t) {
+          constexpr int Tt = decltype(t)::value;
+          const double st = my[j * (LW + 1) + ((rr * RL + Tt) & 15)];
+          Sl[Tt] = 0.5 * (hl[Tt] + st);
+        });
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        sfor<0, RL>([&](auto t) { Sl[decltype(t)::value] = hl[decltype(t)::value]; });
+      }
+      Sl[RL] = (rr == 0) ? snew : 0.0;
+      z = zn;
+      zr = zrn;
+      lhi = lhin;
+      llo = llon;
+    }
+    dtiny = !row_any(dbig, lane);
+#ifdef ALTRO_DIAG_REUSE
+    {
+      const bool same = !row_any(hash != *ah, lane) && (rs->bwmu == mu);
+      const bool first = rs->it == 0;
+      d_same0 += (same && first) ? 1 : 0;
+      d_same1 += (same && !first) ? 1 : 0;
+      d_all0 += first ? 1 : 0;
+      d_all1 += first ? 0 : 1;
+      rs->bwmu = mu;
+    }
+#endif
+    *ah = hash;
   }
 
   // Costate sweep (default mode, box-only problems): lambda_N = l_x(N), lambda_k = l_x(k) + A' lambda_{k+1},
@@ -1331,11 +1732,16 @@ struct Solver {
       s.kref = P.kref;
       s.step = 0;
       s.nbw = s.nro = s.nsolve = s.nit = s.nok = s.ntr = 0;
-      s.bw_plain = 0;
+      s.kmu = P.kmu[inst];
       s.qvalid = 0;
       s.gconf = P.dzero[inst];
       s.ngc = 0;
+      s.nfo = 0;
+#ifdef ALTRO_DIAG_REUSE
+      s.bwmu = -1.0;
+#endif
       *rs = s;
+      *ah = P.ahash[(unsigned)inst * LW + j];
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -1343,7 +1749,15 @@ struct Solver {
       // ---------------- A. rows that begin a solve (one per MPC step, or the single plain solve)
       {
         const int ph = rs->phase;
-        const bool begin = ph == PH_STEP_BEGIN;
+        // Keeping the rows of a wave in step.  A warm MPC solve takes two turns (first iteration, then the confirmation);
+        // a row that needed one more falls out of step with its wave-mates, and from then on EVERY turn of the wave
+        // holds both kinds of work -- two backward passes, two open- and two closed-loop rollouts per step instead of
+        // one (measured on the pass-heavy waves of a grouped launch: 50 passes in 20 steps).  So a row about to begin
+        // a step waits one turn while a wave-mate is in the second turn of its solve: if that solve ends there (it
+        // nearly always does) they begin the next step together.  A mate deep in a hard solve is not waited for.
+        const bool mid = (ph == PH_ITER) && (rs->it == 1) && (rs->iters == 1);
+        const bool hold = !CONES && mpc && (P.resync != 0) && wave_any(mid);
+        const bool begin = (ph == PH_STEP_BEGIN) && !(hold && rs->step < nsteps);
         if (wave_any(begin)) {
           const int stp = rs->step;
           const bool go = begin && (stp < (mpc ? nsteps : 1));
@@ -1384,7 +1798,7 @@ struct Solver {
         const bool ob = rs->phase == PH_OUTER_BEGIN;
         if (wave_any(ob)) {
           ALTRO_STAMP(long long ts = stamp();)
-          const RollOut r0 = rollout<true>(ob, ob && rs->shift != 0);
+          const RollOut r0 = rollout<true>(ob, ob && rs->shift != 0, ob);
           ALTRO_STAMP(t_ro += stamp() - ts;)
           if (ob) {
             const int outer = rs->outer;
@@ -1396,8 +1810,8 @@ struct Solver {
             rs->drho = 0.0;
             rs->dj_zero = 0;
             rs->it = 0;
-            rs->bw_plain = 0;
-            rs->qvalid = 0;
+            rs->qvalid = CONES ? 0 : 1;  // the open-loop rollout left l_z and the active-set hash of its trajectory
+            if constexpr (!CONES) *qhs = r0.qh;
             rs->shift = 0;
             rs->nro += 1;
             rs->J_prev = r0.J;
@@ -1439,40 +1853,98 @@ struct Solver {
           // recompute and its feedforward terms are zero to 0.5e-9 (1 + |u|): the iteration is booked as converged
           // without a backward pass, a rollout or a gradient sweep (see `confirm` below for what the reference does
           // in such an iteration).  Any other outcome falls through to the full iteration.
-          bool gconf = false;
+          bool gconf = false, fo = false, dtiny = false;
           if constexpr (!CONES) {
-            // (same active set as the last backward pass: then its gains ARE the ones the reference's confirmation pass
-            //  would compute -- the problem is quadratic inside an active set, K does not depend on the iterate)
+            // kvalid: the gains in memory ARE the ones a backward pass would compute now -- same active set (hash of the
+            // current trajectory, left by the rollout that produced it, against the hash of the pass that wrote KD), same
+            // penalty, no regularisation.  The problem is quadratic inside an active set, K does not depend on the iterate;
+            // the pass may be one of an earlier solve or an earlier launch (gain reuse).
             const bool same = !row_any(*qhs != *ah, lane);
-            const bool tryg = !o.strict && inner && (rs->it >= 1) && (rs->bw_plain != 0) && (rs->qvalid != 0) && same &&
-                              (rs->rho == 0.0) && (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
+            const bool kvalid = !o.strict && P.reuse && inner && (rs->qvalid != 0) && same && (rs->rho == 0.0) && (rs->kmu == rs->mu);
+            const bool tryg = kvalid && (rs->it >= 1) && (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
             if (wave_any(tryg)) {
               bool gt;
               ALTRO_STAMP(long long ts = stamp();)
               adjoint(gt);
-              ALTRO_STAMP(t_td += stamp() - ts;)
+              ALTRO_STAMP(t_aj += stamp() - ts; c_aj++;)
               gconf = tryg && gt;
             }
+            // ... and an iteration the costate sweep does not settle still skips its backward pass: fosweep() gets the
+            // feedforward terms and dV for the gains in memory
+            fo = kvalid && !gconf;
+            if (wave_any(fo)) {
+              double f1, f2;
+              bool ft;
+              ALTRO_STAMP(long long ts = stamp();)
+              fosweep(fo, f1, f2, ft);
+              ALTRO_STAMP(t_fo += stamp() - ts; c_fo++;)
+              if (fo) {
+                dV1 = f1;
+                dV2 = f2;
+                dtiny = ft;
+                rs->nfo += 1;
+              }
+            }
           }
-          bool bwrow = inner && !gconf;  // rows that run the backward pass of this iteration
+          bool bwrow = inner && !gconf && !fo;  // rows that run the backward pass of this iteration
           // backward pass (with regularisation restarts)
-          bool dtiny = false;
           while (wave_any(bwrow)) {
             bool fail;
             ALTRO_STAMP(long long ts = stamp();)
             const bool with_rho = wave_any(rs->rho != 0.0);
-            if (o.strict) {
-              if (with_rho) backward<true, true>(dV1, dV2, fail, dtiny, bwrow);
-              else backward<false, true>(dV1, dV2, fail, dtiny, bwrow);
+            const unsigned long long bm = __ballot(bwrow);
+            const int nbwr = (int)((bm & 1ull) + ((bm >> 16) & 1ull) + ((bm >> 32) & 1ull) + ((bm >> 48) & 1ull));
+            if (!CONES && P.lone && !with_rho && nbwr == 1) {
+              // exactly one row needs the pass: all four DPP rows work on that row's instance (backward_lone)
+              const int lrow = ((bm >> 16) & 1ull) ? 1 : (((bm >> 32) & 1ull) ? 2 : (((bm >> 48) & 1ull) ? 3 : 0));
+              const int inst_s = inst;
+              const unsigned rowoff_s = rowoff;
+              RowState* const rs_s = rs;
+              double* const sm_s = sm;
+              AHash* const ah_s = ah;
+              inst = __builtin_amdgcn_readlane(inst, lrow * LW);
+              rowoff = (unsigned)inst * LW + j;
+              rs = rs_s - (lane >> 4) + lrow;
+              sm = sm_s - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
+              ah = ah_s - lane + lrow * LW + j;
+              double a1, a2;
+              bool dt;
+              if constexpr (!CONES) {
+                if (o.strict) backward_lone<true>(a1, a2, fail, dt);
+                else backward_lone<false>(a1, a2, fail, dt);
+              }
+              inst = inst_s;
+              rowoff = rowoff_s;
+              rs = rs_s;
+              sm = sm_s;
+              ah = ah_s;
+              if (bwrow) {
+                dV1 = a1;
+                dV2 = a2;
+                dtiny = dt;
+              }
+              n_lone++;
             } else {
-              if (with_rho) backward<true, false>(dV1, dV2, fail, dtiny, bwrow);
-              else backward<false, false>(dV1, dV2, fail, dtiny, bwrow);
+              double b1, b2;
+              bool bt;
+              if (o.strict) {
+                if (with_rho) backward<true, true>(b1, b2, fail, bt, bwrow);
+                else backward<false, true>(b1, b2, fail, bt, bwrow);
+              } else {
+                if (with_rho) backward<true, false>(b1, b2, fail, bt, bwrow);
+                else backward<false, false>(b1, b2, fail, bt, bwrow);
+              }
+              if (bwrow) {
+                dV1 = b1;
+                dV2 = b2;
+                dtiny = bt;
+              }
             }
-            ALTRO_STAMP(t_bw += stamp() - ts;)
+            ALTRO_STAMP(const long long te = stamp() - ts; if (nbwr == 1 && !CONES && P.lone && !with_rho) t_bl += te; else { t_bw += te; c_bw++; })
             if (bwrow) rs->nbw += 1;
             fail = row_any(fail, lane) && bwrow;
             double rho = rs->rho, drho = rs->drho;
-            if (bwrow) rs->bw_plain = (!fail && rho == 0.0) ? 1 : 0;
+            if (bwrow) rs->kmu = (!fail && rho == 0.0) ? rs->mu : -1.0;
             if (fail) {
               if (rho >= o.bp_reg_max) {
                 rs->status = ALTRO_NO_PROGRESS;
@@ -1503,7 +1975,7 @@ struct Solver {
           // below 1e-9 (1 + |u_k,a|) that rollout, its line search and the Todorov sweep cannot change the outcome
           // (same status and iteration count, trajectory within ~1e-8, dJ and gradient far below the tolerances in
           // force), so the iteration is booked as converged on the trajectory it already holds.
-          const bool confirm = gconf || (!o.strict && bwrow && dtiny && (rs->grad_tol > 1e-8) &&
+          const bool confirm = gconf || (!o.strict && (bwrow || fo) && dtiny && (rs->grad_tol > 1e-8) &&
                                          (rs->cost_tol > 1e-10 * (1.0 + fabs(J_prev))));
           bool searching = inner && !confirm, accepted = false, need_interp = false, ls_failed = false;
           if (confirm) {
@@ -1544,7 +2016,7 @@ struct Solver {
           if (wave_any(searching)) {
             ALTRO_STAMP(long long ts = stamp();)
             const RollOut rr = rollout<false>(true, false, searching);
-            ALTRO_STAMP(t_rc += stamp() - ts;)
+            ALTRO_STAMP(t_rc += stamp() - ts; c_rc++;)
             if (searching) {
               rs->nro += 1;
               trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged, rr.tiny);
@@ -1565,7 +2037,7 @@ struct Solver {
             ALTRO_STAMP(long long ts = stamp();)
             Trials T;
             trial_costs(alpha, T);
-            ALTRO_STAMP(t_ls += stamp() - ts;)
+            ALTRO_STAMP(t_ls += stamp() - ts; c_ls++;)
             const double a0 = alpha;
             sfor<0, NA>([&](auto t) {
               constexpr int Tt = decltype(t)::value;
@@ -1686,6 +2158,7 @@ struct Solver {
   }
 
   __device__ void finish() {
+    if (!P.prepare_only) P.ahash[(unsigned)inst * LW + j] = *ah;
     if (j == 0 && !P.prepare_only) {  // a prepare-only launch leaves the statistics of the last solve alone
       P.iters[inst] = rs->iters;
       P.iters_outer[inst] = rs->iters_outer;
@@ -1701,7 +2174,9 @@ struct Solver {
       P.n_iters[inst] += rs->nit;
       P.n_ok[inst] += rs->nok;
       P.n_gconf[inst] += rs->ngc;
+      P.n_fo[inst] += rs->nfo;
       P.dzero[inst] = rs->gconf;
+      P.kmu[inst] = rs->kmu;
     }
   }
 };
@@ -1713,16 +2188,21 @@ template <int NX, int NU, bool CONES>
 __global__ void __launch_bounds__(64, CONES ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
-  __shared__ unsigned hashes[128];
+  __shared__ altro::AHash hashes[128];
   const long long t0 = __builtin_amdgcn_s_memtime();
   Solver<NX, NU, CONES> s(p, rows, tiles, hashes);
   s.run(p.nsteps > 0, p.first_step, p.nsteps);
   s.finish();
   const long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) {
-    long long* wc = p.wave_cycles + (size_t)blockIdx.x * 8;
+    long long* wc = p.wave_cycles + (size_t)blockIdx.x * 16;
     wc[0] = t1 - t0;
-    ALTRO_STAMP(wc[1] = s.t_bw; wc[2] = s.t_rc; wc[3] = s.t_ro; wc[4] = s.t_td; wc[5] = s.t_du; wc[6] = s.t_ls;)
+    ALTRO_STAMP(wc[1] = s.t_bw; wc[2] = s.t_rc; wc[3] = s.t_ro; wc[4] = s.t_td; wc[5] = s.t_du; wc[6] = s.t_ls; wc[8] = s.t_bl; wc[9] = s.t_fo; wc[10] = s.t_aj;
+                wc[11] = s.c_bw; wc[12] = s.c_fo; wc[13] = s.c_aj; wc[14] = s.c_rc; wc[15] = s.c_ls;)
+    wc[7] = s.n_lone;
+#ifdef ALTRO_DIAG_REUSE
+    wc[3] = s.d_same0; wc[4] = s.d_all0; wc[5] = s.d_same1; wc[6] = s.d_all1;
+#endif
   }
 }
 

@@ -67,7 +67,7 @@ struct Params {
   double* trash;        // [B][64] sink for the stores of lanes that hold no element (keeps loop bodies branch-free)
   int *iters, *iters_outer, *status;
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
-  long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf;
+  long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf, *n_gs;
   double* Qz;           // [B][N][n+m] scratch of the costate sweep: gradient of the AL cost at every knot of plane cur
   unsigned* bwst;       // [B][72] gain-reuse state between launches: hash per lane [64], bw_ok, bw_plain, bw_mu (2 words)
   int reuse_ok;         // 0: a setter has changed the model / cost / constraints / options since the last launch
@@ -2370,7 +2370,6 @@ struct Solver {
       // the outcome -- the iteration is booked as converged on the trajectory it holds.
       const bool confirm = gconf || (!o.strict && dtiny && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev))));
       if (confirm && swept) {  // the confirmed iteration ran no backward pass: its feedforward terms are zero
-        ngc++;
         for (int k = 0; k < N - 1; ++k)
           if (T < m) dgi[(size_t)k * m + T] = 0.0;
         block_sync();
@@ -2647,7 +2646,8 @@ struct Solver {
       P.n_solves[inst] += nsolve;
       P.n_iters[inst] += nit;
       P.n_ok[inst] += nok;
-      P.n_gconf[inst] += (ngs > 0 ? ngs : ngc);  // iterations that ran no backward pass
+      P.n_gconf[inst] += ngc;  // iterations booked as converged without a backward pass and a rollout
+      P.n_gs[inst] += ngs;     // iterations that took their gains from memory (adjoint_lds(full) instead of a backward pass)
     }
     {
       unsigned* st = P.bwst + (size_t)inst * 72;
@@ -2701,6 +2701,9 @@ __global__ void __launch_bounds__(64) wide_shift_kernel(Params P, int primal, in
 typedef void (*wide_kernel_t)(Params, int, int, int);
 inline int wide_class(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : 0; }
 inline wide_kernel_t wide_kernel_for(int n, int m) {
+#ifdef ALTRO_DEV_HEADLINE_ONLY  // development builds (tools/build_stamps.sh -DALTRO_DEV_HEADLINE_ONLY): one small instantiation
+  return wide_kernel<4, true>;
+#else
   const bool sm = n <= 16 && m <= 16;
   switch (wide_class(m)) {
     case 4: return sm ? wide_kernel<4, true> : wide_kernel<4, false>;
@@ -2709,6 +2712,7 @@ inline wide_kernel_t wide_kernel_for(int n, int m) {
     case 16: return sm ? wide_kernel<16, true> : wide_kernel<16, false>;
     default: return wide_kernel<0, false>;
   }
+#endif
 }
 
 }  // namespace altro_wide

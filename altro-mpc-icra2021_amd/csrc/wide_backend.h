@@ -57,6 +57,7 @@ struct WideBackend {
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
   unsigned* bwst = nullptr;   // [B][72] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
+  bool debug_keep_gains = false;  // ALTRO_DEBUG_KEEP_GAINS=1 at create time: stale gains are kept (exists to show that the tests notice them)
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
   std::vector<hipEvent_t> bench_ev;
@@ -65,7 +66,7 @@ struct WideBackend {
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr, *noise = nullptr,
          *noise_w = nullptr;
   long long *n_backward = nullptr, *n_rollout = nullptr, *n_trials = nullptr, *n_solves = nullptr, *n_iters = nullptr,
-            *n_ok = nullptr, *n_gconf = nullptr;
+            *n_ok = nullptr, *n_gconf = nullptr, *n_gs = nullptr;
   size_t stage_bytes = 0;
   int Nt = 0, kref = 0, noise_steps = 0, noise_mode = 0, mpc_shift = 1;
   int dyn_blocks = 1, dyn_step_stride = 0;
@@ -109,6 +110,7 @@ struct WideBackend {
     d = *dims;
     o = *opts;
     device = dev;
+    { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); debug_keep_gains = kg && kg[0] == '1'; }
     WCHK(hipSetDevice(device));
     const Lds L = lds_layout(d.n, d.m, kMaxP);
     (void)L;
@@ -125,7 +127,7 @@ struct WideBackend {
     DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 72);
     DA_(iters, B); DA_(iters_outer, B); DA_(status, B); DA_(cost, B); DA_(cmax, B);
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
-    DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B); DA_(n_gconf, B);
+    DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B); DA_(n_gconf, B); DA_(n_gs, B);
     DA_(noise_w, kMaxN); DA_(noise_grp, kMaxN);
     DA_(Lc, 1); DA_(AconT, 1); DA_(bcon, 1); DA_(ctype, 1); DA_(rowk0, 1); DA_(rowk1, 1); DA_(rowc0, 1); DA_(rowcp, 1);
 #undef DA_
@@ -145,7 +147,7 @@ struct WideBackend {
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
-                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, fac, bwst};
+                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, n_gs, fac, bwst};
     for (void* p : ptrs)
       if (p) hipFree(p);
     ring.destroy();
@@ -420,7 +422,7 @@ struct WideBackend {
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
-    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = (gains_valid || getenv("ALTRO_DEBUG_KEEP_GAINS")) ? 1 : 0;  // (the switch exists to show that the tests notice stale gains)
+    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.n_gs = n_gs; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = (gains_valid || debug_keep_gains) ? 1 : 0;
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
@@ -602,7 +604,7 @@ struct WideBackend {
     WCHK(hipStreamSynchronize(stream));
     ring.reset();
     const size_t B = d.batch;
-    for (long long* p : {n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, n_gconf}) WCHK(hipMemset(p, 0, B * sizeof(long long)));
+    for (long long* p : {n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, n_gconf, n_gs}) WCHK(hipMemset(p, 0, B * sizeof(long long)));
     return ALTRO_OK;
   }
   int timing_get(float* ms, int capacity, int* count) {

@@ -145,7 +145,29 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
-def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None):
+def flops_first_order(n, m, N):
+    """first-order sweep of an iteration that takes its gains from memory (include/altro_batch.h,
+    altro_batch_get_reuse_counter): per knot [Qx; Qu] = l_z + [A B]' s, d = -(L D L')^-1 Qu, s = Qx + K' Qu, dV"""
+    return (N - 1) * (2 * n * (n + m) + 2 * n * m + 2 * m * m + 6 * m)
+
+
+def secondary_traffic(key):
+    """HBM bytes of the timed launch of a secondary line from the committed rocprofv3 PMC passes
+    (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_secondary_kernels.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for rec in (t.get(key[0]) or {}).get("launches", []):
+            if key[1] in rec.get("kernel", "") and "hbm_bytes" in rec:
+                best = rec["hbm_bytes"]
+    return best
+
+
+def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None, traffic_key=None):
     """Run W warm-up + K timed MPC steps (one fused launch) of a secondary BASELINE config on one GPU and build
     its JSON line: same metric, roofline from HIP events on the library's stream and the measured pass counts."""
     for i in range(W):
@@ -159,9 +181,13 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
     nb, nr, ntr = altro.work_counters(mp.solver)
     nsol, nit, nok = altro.solve_counters(mp.solver)
     ngc = altro.confirm_counter(mp.solver)
+    nfo = altro.reuse_counter(mp.solver)
+    assert len(ms) == 1, len(ms)
     # roofline.achieved = SURVEY 8(d) flops_solve with the measured iteration and trial counts (as on the headline line);
-    # roofline.executed = the passes the kernel actually ran (iterations settled by a first-order pass run no backward pass)
-    flops_exec = nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N) + ngc.sum() * flops_costate(n, m, N)
+    # roofline.executed = the passes the kernel actually ran: every iteration is a backward pass, a first-order sweep
+    # with the gains in memory, or a costate-sweep confirmation (iterations = nb + nfo + ngc)
+    flops_exec = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N) + ngc.sum() * flops_costate(n, m, N) +
+                  nfo.sum() * flops_first_order(n, m, N))
     flops = nit.sum() * flops_backward(n, m, N) + (nit.sum() + ntr.sum() + B * K) * flops_forward(n, m, N)
     avg_ms = float(ms.mean())
     achieved = flops / len(ms) / (avg_ms * 1e-3) / 1e12
@@ -170,23 +196,36 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic", "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B},
            "roofline": {"bound": bound, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": None, "kernel": kernel, "avg_launch_ms": avg_ms, "launches": int(len(ms)),
+                        "traffic": secondary_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "avg_launch_ms": avg_ms,
+                        "launches": int(len(ms)),
                         "executed": {"achieved": executed, "frac": executed / FP64_PEAK_TFLOPS},
                         "note": "achieved: SURVEY 8(d) flops_solve (measured iterations and trials x the base Riccati / rollout formulas; "
-                                "constraint-expansion flops are not counted); executed: the passes the kernel ran"},
+                                "constraint-expansion flops are not counted) -- an algorithmic rate, NOT hardware utilisation: iterations "
+                                "that take their gains from memory or are confirmed by the costate sweep execute no backward pass; "
+                                "executed: the passes the kernel ran; traffic: HBM bytes of this launch from the committed PMC passes or null"},
            "cpu_baseline": None, "solve_succeeded_frac": float(nok.sum() / max(1, nsol.sum())),
            "iterations_mean": float(nit.sum() / max(1, nsol.sum())), "backward_passes_per_solve": float(nb.sum() / (B * K)),
+           "gains_from_memory_iterations_per_solve": float(nfo.sum() / (B * K)),
+           "costate_confirmed_iterations_per_solve": float(ngc.sum() / (B * K)),
            "rollouts_per_solve": float(nr.sum() / (B * K))}
     if extra:
         out.update(extra)
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def secondary_configs(which, K, W):
-    """BASELINE configs[2..4] on ONE GPU at their per-GPU sizes (not the headline line; `--config` only)."""
+def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
+    """BASELINE configs[2..4] on ONE GPU at their per-GPU sizes.  `--config <name>` prints them as lines of their own; the
+    default run carries short versions (<= 10 steps) inside the headline line's `secondary` list."""
     import altro_amd_loader  # noqa: F401
     import altro_mpc_icra2021_amd as altro
     P, api, mpcm = altro.problems, altro, altro.mpc
+    lines = []
+
+    def done(d):
+        lines.append(d)
+        if emit:
+            emit(d)
+
     if which in ("rocket", "all"):   # configs[2]: rocket landing, second-order cones, N_mpc = 100, batch 4096
         B, Nm, Nt, dt = 4096, 100, 301, 0.05
         K2 = min(K, Nt - Nm - 1 - W)
@@ -203,18 +242,19 @@ def secondary_configs(which, K, W):
         mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, rng.standard_normal((W + K2, B, 6)),
                            (np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])))
         mp.initial_solve()
-        _secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
-                        "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro)
+        done(_secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
+                             "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro, traffic_key=("rocket", "solve_kernel")))
+        mp.solver.close()
     if which in ("state_dim", "all"):   # configs[3]: state-dimension sweep, m = 4, N = 50, 8192 instances per GPU
-        for n in (8, 16, 32, 48, 64):
+        for n in state_dims:
             B = 8192 if n <= 32 else 2048
             K3 = min(K, 10 if n <= 16 else 5)
             pb = P.gen_random_linear_batch(B, n=n, m=4, N=50, steps=K3 + W, seed=10)
             mp = mpcm.BatchMPC(pb)
             mp.initial_solve()
             kern = "altro::solve_kernel<8,4>" if n == 8 else "altro_wide::wide_kernel<4>"
-            _secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
-                            kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro)
+            done(_secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
+                                 kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro))
             mp.solver.close()
     if which in ("quadruped", "all"):   # configs[4]: quadruped contact-switching MPC, N = 40, 2048 instances per GPU, LTV loop on device
         B, N = 2048, 40
@@ -239,8 +279,10 @@ def secondary_configs(which, K, W):
         api.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
         api.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))
         mp.initial_solve()
-        _secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
-                        "altro_wide::wide_kernel<12>", "mfma", 12, 12, N, B, K4, W, mp, altro)
+        done(_secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
+                             "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel")))
+        mp.solver.close()
+    return lines
 
 
 def main():
@@ -250,6 +292,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (the profiling scripts use this)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="K-step regions timed back to back; `value` is the FIRST (W warm-up steps, then exactly K steps), the others are reported beside it")
     ap.add_argument("--config", default="headline", choices=["headline", "rocket", "state_dim", "quadruped", "all"],
                     help="headline (BASELINE configs[1], the driver's line) or a secondary config: extra JSON lines, 1 GPU only")
     ap.add_argument("--steps-per-launch", type=int, default=0,
@@ -266,7 +311,7 @@ def main():
     if a.config != "headline":
         if world != 1:
             sys.exit("secondary configs are single-GPU lines")
-        secondary_configs(a.config, a.steps, a.warmup)
+        secondary_configs(a.config, a.steps, a.warmup, emit=lambda d: print(json.dumps(d), flush=True))
         return
 
     cpu = None
@@ -283,8 +328,8 @@ def main():
     grp = altro.parallel.RankGroup("nccl")
     assert (grp.rank, grp.world) == (rank, world)
 
-    B, K, W = a.batch, a.steps, a.warmup
-    pb = altro.problems.gen_random_linear_batch(B, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=K + W, seed=1,
+    B, K, W, R = a.batch, a.steps, a.warmup, max(1, a.repeats)
+    pb = altro.problems.gen_random_linear_batch(B, n=N_STATE, m=N_CTRL, N=N_KNOT, steps=W + K * R, seed=1,
                                                 first_instance=altro.parallel.shard_first_instance(rank, B))
     mp = altro.mpc.BatchMPC(pb, device=local_rank)
     mp.initial_solve()
@@ -293,23 +338,33 @@ def main():
     altro.timing_reset(mp.solver)
 
     spl = a.steps_per_launch if a.steps_per_launch > 0 else K
-    grp.barrier()
-    t0 = time.perf_counter()
-    i = W
-    while i < W + K:
-        n = min(spl, W + K - i)
-        mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
-        i += n
-    mp.synchronize()
-    grp.barrier()
-    dt = grp.max_over_ranks(time.perf_counter() - t0)
+    launches_per_region = (K + spl - 1) // spl
+    assert launches_per_region * R <= 1024, "more launches than the library's timing ring holds (launch_ring.h CAP)"
+
+    def region(first):
+        """exactly K MPC steps of every instance, bracketed by barrier + synchronize on both sides; max over ranks"""
+        grp.barrier()
+        t0 = time.perf_counter()
+        i = first
+        while i < first + K:
+            n = min(spl, first + K - i)
+            mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
+            i += n
+        mp.synchronize()
+        grp.barrier()
+        return grp.max_over_ranks(time.perf_counter() - t0)
+
+    dt = region(W)                     # THE timed region: W warm-up steps have run, now exactly K steps
 
     st = altro.stats(mp.solver)
     ms = altro.timing_get(mp.solver)
+    assert len(ms) == launches_per_region, (len(ms), launches_per_region)
     nb, nr, ntr = altro.work_counters(mp.solver)
     nsol, nit, nok = altro.solve_counters(mp.solver)
     ngc = altro.confirm_counter(mp.solver)
+    nfo = altro.reuse_counter(mp.solver)
     assert int(nsol.sum()) == B * K, (int(nsol.sum()), B * K)
+    assert int(nb.sum() + nfo.sum() + ngc.sum()) == int(nit.sum())    # every iteration is exactly one of the three kinds
     ok = int(nok.sum())
 
     # final gather of the first controls + status (what an MPC consumer reads each tick): the only
@@ -317,7 +372,22 @@ def main():
     U1 = altro.controls(mp.solver)[:, 0].copy()
     allU, allS = grp.gather(U1, st.status)
     assert allU.shape == (world * B, N_CTRL)
+    # rank r's shard sits at rows [r B, (r+1) B) of the gathered array (a mis-ordered gather shows here)
+    assert np.array_equal(allU[rank * B:(rank + 1) * B], U1) and np.array_equal(allS[rank * B:(rank + 1) * B], st.status)
     ok = grp.sum_over_ranks(ok)
+
+    # the same K-step region R - 1 more times, back to back (later steps of the same closed loops): the spread of the number
+    rep_wall = [dt]
+    for r in range(1, R):
+        rep_wall.append(region(W + r * K))
+    ms_all = altro.timing_get(mp.solver)
+    assert len(ms_all) == launches_per_region * R, (len(ms_all), launches_per_region, R)
+    rep_kernel = [float(ms_all[r * launches_per_region:(r + 1) * launches_per_region].sum()) for r in range(R)]
+
+    secondary = None
+    if rank == 0 and world == 1 and not a.no_secondary:
+        mp.solver.close()
+        secondary = secondary_configs("all", min(K, 10), min(W, 3), state_dims=(8, 16, 32, 64))
 
     if rank == 0:
         n, m, N = N_STATE, N_CTRL, N_KNOT
@@ -327,15 +397,16 @@ def main():
         # source for builder and judge"): flops_solve = sum over the MEASURED inner iterations of [flops_backward +
         # trials x flops_forward] + flops_forward(initial rollout), summed over the solves of one launch -- the
         # arithmetic of the reference's algorithm for the iteration counts the kernel reports (they equal the
-        # oracle's, tests/).  In the default mode about half of those iterations are settled by the costate sweep or
-        # booked as confirmations and do NOT execute a backward pass; what the kernel actually executed is reported
-        # next to it as roofline.executed (measured pass counts x the same formulas), never in its place.
+        # oracle's, tests/).  In the default mode most of those iterations do NOT execute a backward pass (gains taken
+        # from memory, or the costate sweep confirms convergence); what the kernel actually executed is reported
+        # next to it as roofline.executed (measured pass counts x the formulas of each pass), never in its place.
         flops_exec = (nb.sum() * flops_backward(n, m, N) + nr.sum() * flops_forward(n, m, N) +
-                      ngc.sum() * flops_costate(n, m, N)) / max(1, len(ms))
-        flops_launch = (nit.sum() * flops_backward(n, m, N) + (nit.sum() + ntr.sum() + B * K) * flops_forward(n, m, N)) / max(1, len(ms))
-        avg_ms = float(ms.mean()) if len(ms) else float("nan")
+                      ngc.sum() * flops_costate(n, m, N) + nfo.sum() * flops_first_order(n, m, N)) / len(ms)
+        flops_launch = (nit.sum() * flops_backward(n, m, N) + (nit.sum() + ntr.sum() + B * K) * flops_forward(n, m, N)) / len(ms)
+        avg_ms = float(ms.mean())
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-        bytes_launch = B * K * bytes_solve(n, m, N, 2 * m) / max(1, len(ms))
+        bytes_launch = B * K * bytes_solve(n, m, N, 2 * m) / len(ms)
+        rep_rate = sorted(solves / w for w in rep_wall)
         out = {
             "metric": "MPC solves/sec (batched iLQR to tol), random_linear_mpc n=12 m=4 N=50",
             "value": value,
@@ -364,20 +435,28 @@ def main():
                                              "Riccati / rollout formulas) per launch / avg launch duration",
                          "executed": {"achieved": flops_exec / (avg_ms * 1e-3) / 1e12,
                                       "frac": flops_exec / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                                      "note": "flops of the passes the kernel ran (backward passes, rollouts, costate sweeps): "
-                                              "iterations that only confirm convergence run no backward pass in the default mode "
+                                      "note": "flops of the passes the kernel ran (backward passes, rollouts, first-order and costate "
+                                              "sweeps): iterations whose active set and penalty are those of the gains in memory, and "
+                                              "iterations that only confirm convergence, run no backward pass in the default mode "
                                               "(altro_opts.strict = 1 runs them all)"},
                          "hbm_algorithmic_GBps": bytes_launch / (avg_ms * 1e-3) / 1e9,
                          "hbm_frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
+            "repeats": {"regions": R, "steps_each": K, "wall_ms": [1e3 * w for w in rep_wall], "kernel_ms": rep_kernel,
+                        "solves_per_s_median": rep_rate[len(rep_rate) // 2], "solves_per_s_min": rep_rate[0],
+                        "solves_per_s_max": rep_rate[-1],
+                        "note": "`value` is region 0 (W warm-up steps, then exactly K steps); regions 1.. are the next K steps of the "
+                                "same closed loops, each bracketed the same way"},
             "steps_per_launch": spl,
             "solve_succeeded_frac": ok / (world * B * K),
             "iterations_mean": float(nit.sum() / (B * K)),
             "iterations_hist_last_step": np.bincount(st.iterations).tolist(),
             "interp_trials_per_solve": float(ntr.sum() / (B * K)),
             "backward_passes_per_solve": float(nb.sum() / (B * K)),
+            "gains_from_memory_iterations_per_solve": float(nfo.sum() / (B * K)),
             "rollouts_per_solve": float(nr.sum() / (B * K)),
             "costate_confirmed_iterations_per_solve": float(ngc.sum() / (B * K)),
+            "secondary": secondary,
         }
         print(json.dumps(out))
     grp.close()

@@ -254,12 +254,23 @@ int32_t altro_batch_get_work_counters(altro_handle* h, int64_t* backward_passes,
  * SOLVE_SUCCEEDED.  Arrays of `batch` int64; any pointer may be NULL. */
 int32_t altro_batch_get_solve_counters(altro_handle* h, int64_t* solves, int64_t* iterations, int64_t* succeeded);
 /* Per instance since the last timing reset: iLQR iterations of the default (non-strict) mode that were confirmed
- * as converged by the first-order costate sweep instead of a backward pass + rollout (altro_opts.strict).  They
- * are counted in `iterations` but not in `backward_passes`; bench.py prices them at the sweep's own flops. */
+ * as converged by the first-order costate sweep alone -- no backward pass, no first-order sweep with the stored gains,
+ * no rollout (altro_opts.strict).  Every iteration is exactly one of three kinds:
+ * iterations = backward_passes + reused (altro_batch_get_reuse_counter) + confirmed. */
 int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed);
-/* Diagnostic: s_memtime ticks each wave (4 instances) spent in the last solve launch, 8 int64 per
- * wave: total, backward passes, closed-loop rollouts, open-loop rollouts, Todorov gradient,
- * dual update, streaming line-search sweeps, 1 spare.  count = 8 * number of waves. */
+/* Per instance since the last timing reset: iLQR iterations of the default mode that took their gains from memory
+ * instead of running a backward pass -- the active set (hashed knot by knot) and the penalty were those of the pass
+ * that left the gains there, in this solve or an earlier one, and inside a fixed active set K and Quu do not depend
+ * on the trajectory.  Such an iteration runs the first-order recursion (d_k = -Quu^-1 Qu, s_k = Qx + K' Qu, dV) and
+ * then its rollout as usual; counted in `iterations`, not in `backward_passes` (altro_opts.strict = 1: never taken).
+ * Every setter the gains depend on (dynamics, cost, constraints, options) drops them. */
+int32_t altro_batch_get_reuse_counter(altro_handle* h, int64_t* reused);
+/* Diagnostic (16-lane kernels): 16 int64 per wave (4 instances) of the last solve launch.  [0] s_memtime ticks in
+ * total; [7] backward passes the wave ran in the lone-row form (one instance over the four DPP rows).  The
+ * -DALTRO_PHASE_STAMPS build also fills ticks per phase -- [1] four-row backward passes, [2] closed-loop rollouts,
+ * [3] open-loop rollouts, [4] Todorov gradient, [5] dual update, [6] line-search sweeps, [8] lone-row backward passes,
+ * [9] first-order sweeps, [10] costate sweeps -- and how many of each the wave ran: [11] four-row passes, [12]
+ * first-order sweeps, [13] costate sweeps, [14] closed-loop rollouts, [15] trial sweeps.  count = 16 * waves. */
 int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t capacity, int32_t* count);
 
 /* ---- device-resident MPC harness (reference random_linear_problem.jl:121-139, mpc.jl:11-47).

@@ -15,23 +15,25 @@ altro.timing_reset(mp.solver)
 mp.run_async(S, first=5); mp.synchronize()
 ns, ni, nok = altro.solve_counters(mp.solver)
 wcs = altro.wave_cycles(mp.solver).astype(float)
-names = ["total", "backward", "closed", "open", "todorov", "dual", "ls"]
+names = ["total", "bw4", "closed", "open", "todorov", "dual", "ls", "#lone", "bwlone", "fosweep", "adjoint", "#bw4", "#fo", "#aj", "#rc", "#ls"]
 print("steps %d: per-instance iterations mean %.1f max %d; per-wave max-of-4 mean %.1f max %d" % (S, ni.mean(), ni.max(), ni.reshape(-1, 4).max(1).mean(), ni.max()))
 print("wave cycles: mean %.2fM  p50 %.2fM  p99 %.2fM  max %.2fM  -> mean/max = %.3f" % (wcs[:, 0].mean() / 1e6, np.median(wcs[:, 0]) / 1e6, np.percentile(wcs[:, 0], 99) / 1e6, wcs[:, 0].max() / 1e6, wcs[:, 0].mean() / wcs[:, 0].max()))
-print("mean wave  :", " ".join("%s %.2fM" % (n, wcs[:, i].mean() / 1e6) for i, n in enumerate(names)))
+fmt = lambda row: " ".join(("%s %.2fM" % (n, row[i] / 1e6)) if not n.startswith("#") else ("%s %.1f" % (n, row[i])) for i, n in enumerate(names))
+print("mean wave  :", fmt(wcs.mean(0)))
+for nm, ci, ti in (("four-row pass", 11, 1), ("lone pass", 7, 8), ("first-order sweep", 12, 9), ("costate sweep", 13, 10), ("closed rollout", 14, 2), ("trial sweep", 15, 6)):
+    print("  %-18s %.0fk cycles each" % (nm, wcs[:, ti].sum() / max(1.0, wcs[:, ci].sum()) / 1e3))
 st = altro.stats(mp.solver)
 print("kernel ms %.2f" % st.tsolve_ms)
 nb, nr, ntr = altro.work_counters(mp.solver)
 ngc = altro.confirm_counter(mp.solver)
-nbw = nb.reshape(-1, 4).max(1).astype(float)      # backward passes a wave ran = those of its busiest row (roughly)
-print("per wave: backward passes (max row) mean %.1f -> %.0fk cycles per pass, %.0f per knot; costate sweeps mean %.1f -> %.0fk cycles each" % (
-    nbw.mean(), wcs[:, 1].mean() / nbw.mean() / 1e3, wcs[:, 1].mean() / nbw.mean() / (pb.N - 1),
-    ngc.reshape(-1, 4).max(1).mean(), wcs[:, 4].mean() / max(1.0, ngc.reshape(-1, 4).max(1).mean()) / 1e3))
+nfo = altro.reuse_counter(mp.solver)
+print("per solve: iterations %.3f, backward passes %.3f, gains from memory %.3f, costate-confirmed %.3f, rollouts %.3f, trials %.3f; lone passes per wave %.1f" % (
+    ni.sum() / ns.sum(), nb.sum() / ns.sum(), nfo.sum() / ns.sum(), ngc.sum() / ns.sum(), nr.sum() / ns.sum(), ntr.sum() / ns.sum(), wcs[:, 7].mean()))
 # the slowest waves: which phase carries their extra time, and how many turns of the wave loop they took
 order = np.argsort(-wcs[:, 0])[:5]
 nit4 = ni.reshape(-1, 4)
 for w in order:
-    print("wave %5d: %s | row iterations %s" % (w, " ".join("%s %.2fM" % (n, wcs[w, i] / 1e6) for i, n in enumerate(names)), nit4[w].tolist()))
+    print("wave %5d: %s | row iterations %s" % (w, fmt(wcs[w]), nit4[w].tolist()))
 tot_it = nit4.max(1)
 print("cycles per wave-iteration (total / max-of-4 iterations): mean %.0fk, slowest five %s" % (
     (wcs[:, 0] / tot_it).mean() / 1e3, ", ".join("%.0fk" % (wcs[w, 0] / tot_it[w] / 1e3) for w in order)))
