@@ -2,6 +2,7 @@
 # Register / scratch / LDS use of the headline kernel instantiation (compiles solve_dpp16.h alone: ~6 s).
 #   tools/kernel_meta.sh [NX NU CONES] [extra -D flags]
 NX=${1:-12}; NU=${2:-4}; CO=${3:-false}; shift 3 2>/dev/null
+python3 "$(dirname "$0")/../altro-mpc-icra2021_amd/csrc/gen_dpp_blocks.py" "$(dirname "$0")/../altro-mpc-icra2021_amd/csrc/dpp_blocks.inc"
 T=$(mktemp -d)
 cat > $T/one.hip <<EOT
 #include "$(cd "$(dirname "$0")/.." && pwd)/altro-mpc-icra2021_amd/csrc/solve_dpp16.h"
