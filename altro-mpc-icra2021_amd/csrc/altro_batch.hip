@@ -352,7 +352,7 @@ __global__ void k_group_score(const double* __restrict__ Zref, const double* __r
 }
 
 // perm[rank of instance i among (score, i)] = i: a deterministic sort by counting (Bp^2 compares: microseconds)
-__global__ void k_group_rank(const int* __restrict__ score, int* __restrict__ perm, int Bp) {
+__global__ void k_group_rank(const int* __restrict__ score, int* __restrict__ perm, int Bp, int mode) {
   __shared__ int tile[1024];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int si = i < Bp ? score[i] : 0;
@@ -367,7 +367,17 @@ __global__ void k_group_rank(const int* __restrict__ score, int* __restrict__ pe
     }
     __syncthreads();
   }
-  if (i < Bp) perm[rank] = i;
+  if (i < Bp) {
+    const int W = Bp / 4;
+    int slot = rank;                                  // mode 1: sorted, the instances with the fewest expected passes first
+    if (mode == 2) {                                  // sorted waves, light and heavy ones alternating in the block order
+      const int wr = rank / 4, q = rank % 4;
+      slot = ((wr < W / 2) ? 2 * wr : 2 * (W - 1 - wr) + 1) * 4 + q;
+    } else if (mode == 3) {                           // every wave gets one instance of each quartile
+      slot = (rank % W) * 4 + rank / W;
+    }
+    perm[slot] = i;
+  }
 }
 
 __global__ void k_fill(double* p, double v, size_t nelem) {
@@ -407,10 +417,13 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.perm = nullptr;
   // fused MPC launches of box-constrained problems: group the instances by how many of the launch's steps will need
   // backward passes (see k_group_score); everything else runs in instance order
-  if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
+  // (short launches only: over 100 steps nearly every window meets a bound at some point, the score stops separating the
+  //  instances and clustering the pass-heavy rows -- they are also the ones with the hard solves -- lengthens the tail:
+  //  measured 20 steps +2 %, 100 steps -3 %, tools/gpu_ab.py)
+  if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && nsteps <= 32 && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
     hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
                        first_step, nsteps, h->box_k0, h->box_k1, h->d.n + h->d.m);
-    hipLaunchKernelGGL(k_group_rank, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp);
+    hipLaunchKernelGGL(k_group_rank, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp, h->group);
     p.perm = h->perm;
   }
   const dim3 grid(h->Bp / IPW), block(64);
@@ -570,6 +583,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
     { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
     { const char* ng = getenv("ALTRO_NO_GROUP"); h->group = (ng && ng[0] == '1') ? 0 : 1; }
+    { const char* gm = getenv("ALTRO_GROUP_MODE"); if (gm && gm[0] >= '0' && gm[0] <= '3') h->group = gm[0] - '0'; }
     { const char* nr = getenv("ALTRO_NO_REUSE"); h->reuse = (nr && nr[0] == '1') ? 0 : 1; }
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {

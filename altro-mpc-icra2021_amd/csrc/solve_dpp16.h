@@ -51,6 +51,9 @@
 #ifndef ALTRO_PD_ADJOINT
 #define ALTRO_PD_ADJOINT 8  // knots of prefetch in the costate sweep (one load per knot)
 #endif
+#ifndef ALTRO_PD_FOSWEEP
+#define ALTRO_PD_FOSWEEP 4  // knots of prefetch in the first-order sweep (2 + NU loads per knot)
+#endif
 #ifndef ALTRO_UN
 #define ALTRO_UN 4           // knots per chunk in the streaming sweeps
 #endif
@@ -1291,7 +1294,7 @@ struct Solver {
     dV1 = 0.0;
     dV2 = 0.0;
     double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
-    constexpr int PD = 4;
+    constexpr int PD = ALTRO_PD_FOSWEEP;
     struct In {
       double qz, z, kr[NU];
     };
@@ -1860,7 +1863,7 @@ struct Solver {
             // penalty, no regularisation.  The problem is quadratic inside an active set, K does not depend on the iterate;
             // the pass may be one of an earlier solve or an earlier launch (gain reuse).
             const bool same = !row_any(*qhs != *ah, lane);
-            const bool kvalid = !o.strict && P.reuse && inner && (rs->qvalid != 0) && same && (rs->rho == 0.0) && (rs->kmu == rs->mu);
+            const bool kvalid = !o.strict && inner && (rs->qvalid != 0) && same && (rs->rho == 0.0) && (rs->kmu == rs->mu);
             const bool tryg = kvalid && (rs->it >= 1) && (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
             if (wave_any(tryg)) {
               bool gt;
@@ -1871,7 +1874,7 @@ struct Solver {
             }
             // ... and an iteration the costate sweep does not settle still skips its backward pass: fosweep() gets the
             // feedforward terms and dV for the gains in memory
-            fo = kvalid && !gconf;
+            fo = kvalid && !gconf && (P.reuse != 0);
             if (wave_any(fo)) {
               double f1, f2;
               bool ft;
