@@ -88,8 +88,9 @@ def test_wide_kernel_strict_option_and_default_shortcuts(oracle, n, m, N):
         runs.append((np.array(x0s), np.array(u1s), np.array(its), np.array(sts), float((nr + ntr).sum())))
     (xa, ua, ia, sa, ra), (xb, ub, ib, sb, rb) = runs
     assert np.array_equal(sa, sb) and np.all(sa == altro.SOLVE_SUCCEEDED)
-    assert (ia != ib).mean() <= 5e-3, (ia != ib).mean()
-    assert rel_err(xa, xb) <= RTOL and rel_err(ua, ub) <= RTOL, (rel_err(xa, xb), rel_err(ua, ub))
+    # observed: no count differs, closed loops equal to 1e-14 (the shortcuts only skip work whose result is known)
+    assert np.array_equal(ia, ib), (ia != ib).mean()
+    assert rel_err(xa, xb) <= 1e-12 and rel_err(ua, ub) <= 1e-12, (rel_err(xa, xb), rel_err(ua, ub))
     assert ra < 0.8 * rb, (ra, rb)
     print("wide kernel (%d,%d), strict vs default over %d x %d solves: iteration counts differ in %.3f %%, x0 %.1e, u1 %.1e; rollouts %.0f vs %.0f" % (
         n, m, B, S, 100 * (ia != ib).mean(), rel_err(xa, xb), rel_err(ua, ub), rb, ra))
@@ -116,11 +117,12 @@ def test_wide_kernel_quadruped_strict_equals_default():
         out.append((np.array(its), altro.stats(mp.solver).status.copy(), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()))
     (ia, sa, Xa, Ua, xa), (ib, sb, Xb, Ub, xb) = out
     assert np.array_equal(sa, sb)
-    assert (ia != ib).mean() <= 1e-2, (ia != ib).mean()
-    assert rel_err(Xa, Xb) <= RTOL and rel_err(Ua, Ub) <= RTOL and rel_err(xa, xb) <= RTOL
+    print("quadruped strict vs default: iteration counts differ in %.3f %%, X %.1e, U %.1e, x0 %.1e" % (100 * (ia != ib).mean(), rel_err(Xa, Xb), rel_err(Ua, Ub), rel_err(xa, xb)))
+    assert np.array_equal(ia, ib), (ia != ib).mean()
+    assert rel_err(Xa, Xb) <= 1e-9 and rel_err(Ua, Ub) <= 1e-9 and rel_err(xa, xb) <= 1e-9
 
 
-@pytest.mark.parametrize("n,m,N", [(12, 4, 50), (6, 3, 21), (6, 6, 31), (8, 4, 11)])
+@pytest.mark.parametrize("n,m,N", [(12, 4, 50), (6, 3, 21), (6, 6, 31), (8, 4, 11), (8, 4, 50)])
 def test_mpc_loop_matches_oracle(oracle, n, m, N):
     """Warm-started MPC loop (reference run_MPC order) for every built kernel size."""
     B, S = 10, 8   # B not a multiple of 4: exercises the padded instance slots
@@ -291,14 +293,16 @@ def test_quadruped_ltv_mpc_runs_device_resident(oracle, N):
     assert np.array_equal(fused.x0(), x0g)
 
 
-def test_quadruped_full_batch_properties_and_sampled_parity(oracle):
+@pytest.mark.parametrize("lin", [True, False])
+def test_quadruped_full_batch_properties_and_sampled_parity(oracle, lin):
     """BASELINE configs[4] at its per-GPU size: quadruped contact-switching MPC, N = 40, batch 2048 (16384 over 8
-    GPUs), three ticks device-resident.  The oracle follows a strided sample; the whole batch is checked through
+    GPUs), three ticks device-resident, with either friction form ALTROParams.jl:67-72 can build (lin: linearised
+    pyramids, C8; otherwise second-order cones, C4).  The oracle follows a strided sample; the whole batch is checked through
     size-independent properties: every status SOLVE_SUCCEEDED, 0 <= f_z <= 133 and the friction pyramids to the
     constraint tolerance, the per-knot affine dynamics satisfied, x_1 == x0 exactly, instance results independent of
     the batch around them."""
     B, S, N = 2048, 3, 40
-    qp = P.gen_quadruped_problem(N=N)
+    qp = P.gen_quadruped_problem(N=N, linearized_friction=lin)
     rng = np.random.default_rng(17)
     t0 = rng.uniform(0.0, 0.8, B)
     x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
@@ -322,11 +326,20 @@ def test_quadruped_full_batch_properties_and_sampled_parity(oracle):
     for i in range(S):
         mp.step(i)
         st, X, U, x0g = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), mp.x0()
-        assert np.all(st.status == altro.SOLVE_SUCCEEDED), np.bincount(st.status)
+        ok = st.status == altro.SOLVE_SUCCEEDED
+        # (second-order friction cones: up to 1 % of the 2048 solves per tick end at the cost or outer-iteration limit, in the
+        #  oracle as on the GPU, same iteration counts: tools/debug/gpu_quad_soc_fail.py; the sample below is compared status
+        #  for status)
+        assert np.all(ok) if lin else ok.mean() >= 0.985, np.bincount(st.status)
         assert np.array_equal(X[:, 0], x0g)
+        X, U, okX = X, U, ok
         fx, fy, fz = U[:, :, 0::3], U[:, :, 1::3], U[:, :, 2::3]
+        fx, fy, fz = fx[ok], fy[ok], fz[ok]
         assert fz.min() >= -tol and fz.max() <= qp.fz_max + tol
-        assert (np.abs(fx) - qp.mu * fz).max() <= tol and (np.abs(fy) - qp.mu * fz).max() <= tol
+        if lin:
+            assert (np.abs(fx) - qp.mu * fz).max() <= tol and (np.abs(fy) - qp.mu * fz).max() <= tol
+        else:
+            assert (np.hypot(fx, fy) - qp.mu * fz).max() <= 2 * tol
         Aw, Bw, dw = A[:, i + 1:i + N], Bm[:, i + 1:i + N], d[:, i + 1:i + N]
         Xn = np.einsum("bkij,bkj->bki", Aw, X[:, :-1]) + np.einsum("bkij,bkj->bki", Bw, U) + dw
         assert np.abs(Xn - X[:, 1:]).max() <= 1e-11 * max(1.0, np.abs(X).max())
@@ -335,13 +348,47 @@ def test_quadruped_full_batch_properties_and_sampled_parity(oracle):
             o.set_dynamics(A[b, i + 1:i + N], Bm[b, i + 1:i + N], d[b, i + 1:i + N])
             o.set_initial_state(xn)
             o.shift_fill(True, True)
-            check_against_oracle(st, X, U, b, o, o.solve())
+            so = o.solve()
+            if lin:
+                check_against_oracle(st, X, U, b, o, so)
+            else:
+                # A swing leg's force sits at the APEX of its friction cone (f = 0 to rounding), where the three branches
+                # of the projection meet: which one a knot takes -- and with it the first step of the solve -- is decided
+                # by the last bit (tools/debug/gpu_quad_soc_trace.py: identical traces for ticks on end, then one solve
+                # whose first iterate differs by 3e-6 and which ends at the same optimum).  Compared here: the status and,
+                # for solves that succeed on both sides, the optimum they reach.
+                assert int(st.status[b]) == so.status
+                if so.status == 1:
+                    assert abs(st.cost[b] - so.cost) <= RTOL * max(1.0, abs(so.cost))
+                    assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-4
     sub = np.array([5, 1000, B - 1])
     mp2 = _quadruped_device_loop(qp, x0[sub], A[sub], Bm[sub], d[sub], noise[:, sub], S)
     mp2.initial_solve()
     mp2.run_async(S, first=0)
     mp2.synchronize()
     assert np.array_equal(altro.states(mp2.solver), X[sub]) and np.array_equal(altro.controls(mp2.solver), U[sub])
+
+
+def test_grasp_cold_solve_at_the_reference_horizon(oracle):
+    """The cold grasp solve at the size the benchmark script runs it (grasp_benchmark.jl:72: GraspProblem(o, 251),
+    tf = 6 s) through the C-ABI against the oracle: a batch of perturbed initial states; per-knot equality,
+    inequality and second-order-cone rows plus the goal at knot 251."""
+    gp = P.gen_grasp_problem(N=251, tf=6.0)
+    opts = dict(cost_tolerance=1e-6, cost_tolerance_intermediate=1e-4, constraint_tolerance=1e-6,
+                iterations=5000, iterations_outer=60, iterations_inner=300)
+    B = 6
+    rng = np.random.default_rng(11)
+    x0 = np.tile(gp.x0, (B, 1))
+    x0[1:, 1:3] += 0.1 * rng.standard_normal((B - 1, 2))      # instance 0 is the reference's problem
+    sv = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0), altro.SolverOptions(**opts))
+    altro.solve(sv)
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    assert np.all(st.status == altro.SOLVE_SUCCEEDED)
+    for b in range(B):
+        o = rocket_oracle(oracle, gp, x0[b], opts)
+        so = o.solve()
+        assert so.status == 1
+        check_against_oracle(st, X, U, b, o, so, utol=1e-5, ttol=1e-5)
 
 
 @pytest.mark.parametrize("n,B", [(16, 8192), (32, 8192), (48, 2048), (64, 2048)])
@@ -477,8 +524,9 @@ def test_strict_option_matches_oracle_and_bounds_the_default_shortcuts(oracle):
         runs.append((np.array(x0s), np.array(u1s), np.array(its), np.array(sts), altro.timing_get(mp.solver).sum()))
     (xa, ua, ia, sa, ta), (xb, ub, ib, sb, tb) = runs
     assert np.array_equal(sa, sb) and np.all(sa == altro.SOLVE_SUCCEEDED)
-    assert (ia != ib).mean() <= 5e-3, (ia != ib).mean()
-    assert rel_err(xa, xb) <= RTOL and rel_err(ua, ub) <= RTOL, (rel_err(xa, xb), rel_err(ua, ub))
+    # observed: no count differs, closed loops equal to 1e-14 (the shortcuts only skip work whose result is known)
+    assert np.array_equal(ia, ib), (ia != ib).mean()
+    assert rel_err(xa, xb) <= 1e-12 and rel_err(ua, ub) <= 1e-12, (rel_err(xa, xb), rel_err(ua, ub))
     print("strict vs default over %d x %d solves: iteration counts differ in %.3f %%, closed-loop x0 %.1e, u1 %.1e; kernel time %.1f vs %.1f ms" % (
         B, S, 100 * (ia != ib).mean(), rel_err(xa, xb), rel_err(ua, ub), tb, ta))
 
