@@ -86,7 +86,7 @@ struct altro_handle {
   int bslot_h[LW];       // host copy: slot of z element j among the bounded ones, -1 if none
   int nbp = 1;           // slots per side of the compact dual rows
   int ncon = 0;
-  bool have_dyn = false, have_cost = false, have_ref = false;
+  bool have_dyn = false, have_cost = false, have_ref = false, have_x0 = false;
   bool dyn_per_instance = false;
   double dt = 0.0;
   std::string err;
@@ -557,6 +557,11 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       altro_handle* hw = new (std::nothrow) altro_handle();
       altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
       if (!hw || !wb) { g_create_err = "out of host memory"; delete hw; delete wb; return ALTRO_ERR_INVALID_ARG; }
+      struct WOwner {  // releases both on every path out of this block (exceptions included) unless handed over
+        altro_handle* hw;
+        altro_wide::WideBackend* wb;
+        ~WOwner() { if (wb) { wb->destroy(); delete wb; } delete hw; }
+      } wo{hw, wb};
       altro_opts o0;
       if (opts) o0 = *opts; else altro_default_opts(&o0);
       hw->d = *dims;
@@ -565,17 +570,22 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       const int rc = wb->create(dims, &o0, device);
       if (rc) {
         g_create_err = wb->err;
-        wb->destroy();
-        delete wb;
-        delete hw;
         return rc;
       }
       hw->wide = wb;
+      wo.hw = nullptr;
+      wo.wb = nullptr;
       *out = hw;
       return ALTRO_OK;
     }
     altro_handle* h = new (std::nothrow) altro_handle();
     if (!h) { g_create_err = "out of host memory"; return ALTRO_ERR_INVALID_ARG; }
+    // anything that throws below (std::vector::assign, std::string) unwinds through this guard: the handle, its stream,
+    // events and every array allocated so far are released before guard() turns the exception into an error code
+    struct Owner {
+      altro_handle* p;
+      ~Owner() { if (p) altro_batch_destroy(p); }
+    } owner{h};
     h->d = *dims;
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
@@ -588,8 +598,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {
       g_create_err = std::string(what) + ": " + hipGetErrorString(er);
-      altro_batch_destroy(h);
-      return ALTRO_ERR_HIP;
+      return ALTRO_ERR_HIP;      // (the Owner releases the handle)
     };
   #define CCHK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) return fail(#call, e2); } while (0)
     CCHK(hipSetDevice(device));
@@ -604,7 +613,6 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     // the kernels address every array with 32-bit element offsets
     if ((2 * N + 1) * row * sizeof(double) >= (1ull << 32) || N * Bp * m * LW * sizeof(double) >= (1ull << 32)) {
       g_create_err = "batch * N too large for one handle (arrays must stay below 4 GiB); split the batch";
-      altro_batch_destroy(h);
       return ALTRO_ERR_UNSUPPORTED;
     }
     CCHK(hipMalloc(&h->Gcol, Bp * n * LW * sizeof(double)));
@@ -709,6 +717,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     hipLaunchKernelGGL(k_fill, grid_for(Bp), dim3(256), 0, h->stream, h->kmu, -1.0, (size_t)Bp);  // no gains yet
     CCHK(hipStreamSynchronize(h->stream));
   #undef CCHK
+    owner.p = nullptr;
     *out = h;
     return ALTRO_OK;
   });
@@ -767,6 +776,22 @@ static int migrate_to_wide(altro_handle* h) {
     wb->destroy();
     delete wb;
     return rc;
+  }
+  if (h->have_x0) {  // an initial state uploaded before the model: carried over, not dropped
+    std::vector<double> x((size_t)h->d.batch * h->d.n);
+    int rcx = ensure_stage(h, x.size() * sizeof(double));
+    if (!rcx) {
+      hipLaunchKernelGGL(k_unpack_x0, grid_for((size_t)h->d.batch * LW), dim3(256), 0, h->stream, h->stage, h->x0, h->d.batch, h->d.n);
+      if (hipMemcpyAsync(x.data(), h->stage, x.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess) rcx = ALTRO_ERR_HIP;
+    }
+    if (!rcx) rcx = wb->set_initial_state(x.data());
+    if (rcx) {
+      h->err = rcx == ALTRO_ERR_HIP ? "copying the initial state to the wide backend failed" : wb->err;
+      wb->destroy();
+      delete wb;
+      return rcx;
+    }
   }
   free_dpp_backend(h);
   h->wide = wb;
@@ -1014,6 +1039,7 @@ int32_t altro_batch_set_initial_state(altro_handle* h, const double* x0) {
                        h->Bp, h->d.n);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_x0 = true;
     return ALTRO_OK;
   });
 }

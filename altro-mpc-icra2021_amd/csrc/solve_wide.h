@@ -69,7 +69,7 @@ struct Params {
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
   long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf, *n_gs;
   double* Qz;           // [B][N][n+m] scratch of the costate sweep: gradient of the AL cost at every knot of plane cur
-  unsigned* bwst;       // [B][72] gain-reuse state between launches: hash per lane [64], bw_ok, bw_plain, bw_mu (2 words)
+  unsigned* bwst;       // [B][136] gain-reuse state between launches: hash per lane [2][64], bw_ok, bw_plain, bw_mu (2 words)
   int reuse_ok;         // 0: a setter has changed the model / cost / constraints / options since the last launch
   double* fac;          // [B][N][MC (MC + 1) / 2] (n, m <= 16) L D L' factor of Quu_k of the last backward pass: strictly lower
                         // triangle of L and 1 / D on the diagonal, row-major packed (costate sweep)
@@ -337,7 +337,7 @@ struct Solver {
   bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
   // costate sweep (adjoint_row): per-lane active-set hashes of the last backward pass and of the trajectory whose
   // plane cur holds; bw_plain: that pass ran without regularisation; qvalid: q_hash describes plane cur
-  unsigned bw_hash = 0u, q_hash = 0u;
+  unsigned long long bw_hash = 0ull, q_hash = 0ull;  // 64 bits per lane: two independent 32-bit sums (hash_add)
   bool bw_plain = false, qvalid = false;
   bool bw_ok = false;  // Kg and fac hold a backward pass that succeeded (generic class: kept across the solves of a launch)
   double bw_mu = 0.0;  // the penalty it ran at
@@ -578,7 +578,7 @@ struct Solver {
     bool limit;
     bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
     bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
-    unsigned qh;     // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
+    unsigned long long qh;  // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
   };
 
   // ---- second-order cone rows (oracle soc_project / con_cost / cost_expansion) -------------
@@ -832,7 +832,7 @@ struct Solver {
     const double fT = fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
-    unsigned qh = 0u;  // active-set hash of the trajectory produced (costate sweep)
+    unsigned long long qh = 0ull;  // active-set hash of the trajectory produced (costate sweep)
     double xb = isx ? x0i[Tn] : 0.0;
     struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
     auto ld = [&](int k) {
@@ -967,7 +967,7 @@ struct Solver {
     double ab[32];  // row t of [A B]: time-invariant dynamics keep it for the whole rollout, per-knot ones refill it
 #pragma unroll
     for (int c = 0; c < 32; ++c) ab[c] = abrow[c];
-    unsigned qh = 0u;
+    unsigned long long qh = 0ull;
     double fT = LTV ? 0.0 : fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
@@ -1630,7 +1630,7 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = !open && !wave_any(chg);
     r.tiny = !open && !wave_any(big);
-    r.qh = 0u;
+    r.qh = 0ull;
     return r;
   }
 
@@ -1661,9 +1661,14 @@ struct Solver {
   // Active-set hash of one lane: a position-weighted sum of the per-knot codes, so that the backward pass (knots in
   // descending order) and a rollout (ascending) arrive at the same number for the same active set.  Code of lane T at
   // a knot: bits 0-1 the box sides of x_T that enter the Hessian, bits 2-3 those of u_T, bit 4 generic row T active.
-  static __device__ __forceinline__ unsigned hash_add(unsigned h, unsigned code, int k) {
-    const unsigned mk = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;
-    return __umul24(code, mk) + h;
+  // Two independent 32-bit sums packed into 64 bits: the hash of the gains in memory is compared with the active sets
+  // of unrelated later solves, launch after launch (gain reuse), so a collision must be out of reach.
+  static __device__ __forceinline__ unsigned long long hash_add(unsigned long long h, unsigned code, int k) {
+    const unsigned ka = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;
+    const unsigned kb = (((unsigned)(2 * k + 1)) * 2246822519u) >> 8;
+    const unsigned a = (unsigned)h + __umul24(code, ka);
+    const unsigned b = (unsigned)(h >> 32) + __umul24(code, kb);
+    return ((unsigned long long)b << 32) | (unsigned long long)a;
   }
   static __device__ __forceinline__ unsigned box_code(double z, double zmx, double zmn, double lhi, double llo, bool on) {
     const bool bh = on & (zmx < 1e300), bl = on & (zmn > -1e300);
@@ -1949,7 +1954,8 @@ struct Solver {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
-    unsigned hash = 0u, kcode = 0u;
+    unsigned long long hash = 0ull;
+    unsigned kcode = 0u;
     expansion(N - 1, true, load_knot(N - 1, true, 2, Xp(cur), Up(cur)), kcode);
     hash = hash_add(hash, kcode, N - 1);
     if (T < n) {
@@ -2363,7 +2369,7 @@ struct Solver {
       J = __builtin_inf();
       int ls = 0;
       bool accepted = true;
-      unsigned qh_acc = 0u;
+      unsigned long long qh_acc = 0ull;
       // Default-mode shortcuts, the ones of solve_dpp16.h (altro_opts.strict = 1 takes none of them).  Confirmation
       // iteration: every feedforward term of the backward pass is at rounding level, so the rollout, its line search
       // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
@@ -2596,11 +2602,11 @@ struct Solver {
     kref = P.kref;
     nbw = nro = ntr = 0;
     {  // the gain-reuse state of the previous launch (one launch of K steps and K launches of one step decide alike)
-      const unsigned* st = P.bwst + (size_t)inst * 72;
-      bw_hash = st[T];
-      bw_ok = P.reuse_ok != 0 && st[64] != 0u;
-      bw_plain = st[65] != 0u;
-      bw_mu = __hiloint2double((int)st[67], (int)st[66]);
+      const unsigned* st = P.bwst + (size_t)inst * 136;
+      bw_hash = ((unsigned long long)st[64 + T] << 32) | (unsigned long long)st[T];
+      bw_ok = P.reuse_ok != 0 && st[128] != 0u;
+      bw_plain = st[129] != 0u;
+      bw_mu = __hiloint2double((int)st[131], (int)st[130]);
     }
     long long nsolve = 0, nit = 0, nok = 0;
     if (!P.ltv) load_dyn(0);                                   // time-invariant dynamics stay resident in LDS
@@ -2650,13 +2656,14 @@ struct Solver {
       P.n_gs[inst] += ngs;     // iterations that took their gains from memory (adjoint_lds(full) instead of a backward pass)
     }
     {
-      unsigned* st = P.bwst + (size_t)inst * 72;
-      st[T] = bw_hash;
+      unsigned* st = P.bwst + (size_t)inst * 136;
+      st[T] = (unsigned)bw_hash;
+      st[64 + T] = (unsigned)(bw_hash >> 32);
       if (T == 0) {
-        st[64] = bw_ok ? 1u : 0u;
-        st[65] = bw_plain ? 1u : 0u;
-        st[66] = (unsigned)__double2loint(bw_mu);
-        st[67] = (unsigned)__double2hiint(bw_mu);
+        st[128] = bw_ok ? 1u : 0u;
+        st[129] = bw_plain ? 1u : 0u;
+        st[130] = (unsigned)__double2loint(bw_mu);
+        st[131] = (unsigned)__double2hiint(bw_mu);
       }
     }
     coop_quit();  // releases the helper waves of a cooperative block: the ONLY exit of run(), reached on every path

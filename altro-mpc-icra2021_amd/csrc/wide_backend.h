@@ -56,7 +56,7 @@ struct WideBackend {
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
-  unsigned* bwst = nullptr;   // [B][72] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
+  unsigned* bwst = nullptr;   // [B][136] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
   bool debug_keep_gains = false;  // ALTRO_DEBUG_KEEP_GAINS=1 at create time: stale gains are kept (exists to show that the tests notice them)
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
@@ -124,7 +124,7 @@ struct WideBackend {
 #define DA_(p, c) if ((rc = dalloc(&p, (c)))) return rc
     DA_(wd, z); DA_(wf, n); DA_(zmin, z); DA_(zmax, z);
     DA_(x0, B * n); DA_(X, B * 2 * N * n); DA_(U, B * 2 * (N - 1) * m); DA_(cur, B);
-    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 72);
+    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 136);
     DA_(iters, B); DA_(iters_outer, B); DA_(status, B); DA_(cost, B); DA_(cmax, B);
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
     DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B); DA_(n_gconf, B); DA_(n_gs, B);

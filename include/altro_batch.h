@@ -241,7 +241,9 @@ int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d);
 int32_t altro_batch_last_solve_ms(altro_handle* h, float* ms);
 /* Launch-duration history of the solve kernel (HIP events recorded on the handle's stream around
  * every solve launch since the last reset): the measurement behind bench.py's roofline figure.
- * reset also clears the work counters below.  Synchronises the stream. */
+ * reset also clears the work counters below.  Synchronises the stream.  timing_get returns the most recent
+ * launches, at most 1024 of them (launch_ring.h CAP); the work counters keep accumulating over ALL launches since the
+ * reset, so a caller that relates the two (bench.py) must stay within 1024 launches per reset (it asserts so). */
 int32_t altro_batch_timing_reset(altro_handle* h);
 int32_t altro_batch_timing_get(altro_handle* h, float* ms, int32_t capacity, int32_t* count);
 /* Work done since the last timing reset, per instance: iLQR backward passes, rollouts (open-loop
