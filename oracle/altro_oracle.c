@@ -82,6 +82,12 @@ void orc_default_opts(orc_opts* o) {
   o->bp_reg = 0;
   o->soc_second_order = 1;
   o->kickout_max_penalty = 0;
+  o->projected_newton = 0;
+  o->projected_newton_tolerance = 1e-3;
+  o->active_set_tolerance_pn = 1e-3;
+  o->rho_chol = 1e-2;
+  o->rho_primal = 1e-8;
+  o->r_threshold = 1.1;
 }
 
 /* ---------------------------------------------------------------- lifecycle */
@@ -814,10 +820,366 @@ static double penalty_max_now(const orc_solver* s) {
   return v;
 }
 
+/* ---------------------------------------------------------------- projected-Newton polish
+ * solve!(::ProjectedNewtonSolver) of Altro.jl [PKG]; ALTRO (Howell, Jackson, Manchester, IROS 2019) Algorithm 4.
+ * PARITY UNPINNED: no output of the polish is stored in the reference.
+ *
+ * Primal variables z = (x_0, u_0, ..., x_{N-1}); constraints d(z) = 0: the initial condition x_0 - x0, the dynamics
+ * defects A x_k + B u_k + f - x_{k+1}, and the ACTIVE rows of the problem's constraints (equalities; inequality rows
+ * with c >= -active_set_tolerance_pn; a second-order cone (v, t) through h = ||v|| - t with the same test).  One
+ * projection step is the minimum-norm correction in the metric of the cost Hessian H (diagonal here, + rho_primal):
+ *     dz = -H^-1 D' (D H^-1 D')^-1 d,      S = D H^-1 D'
+ * S is block tridiagonal over the knots (block k: [initial condition if k = 0; active stage rows of knot k; defect k]),
+ * factored as S + rho_chol I = L L' block by block; reg_solve refines the solution against S itself.  A step is
+ * accepted if it lowers ||d||_inf (else halved, at most 10 times); the same factors serve further steps while
+ * log(viol)/log(viol_prev) stays above r_threshold; the active set and the linearisation are renewed up to 10 times. */
+typedef struct {
+  int bmax;        /* rows a block can hold */
+  int* nb;         /* [N] rows of block k */
+  int* nst;        /* [N] of which stage rows (after the n initial-condition rows of block 0) */
+  int* rcon;       /* [N][bmax] constraint index of a stage row */
+  int* rrow;       /* [N][bmax] row inside that constraint (SOC: 0) */
+  double* E;       /* [N][bmax][nz]  Jacobian of block k wrt z_k */
+  double* dv;      /* [N][bmax] values */
+  double* Ld;      /* [N][bmax][bmax] diagonal Cholesky blocks (lower) */
+  double* Lo;      /* [N][bmax][bmax] L_{k,k-1} (rows of block k, columns of block k-1) */
+  double* hinv;    /* [N][nz] 1 / (H + rho_primal) */
+} pn_ws;
+
+static double* pn_hdiag(const orc_solver* s, int k, double* h) {
+  int n = s->n, m = s->m;
+  for (int i = 0; i < n; ++i) h[i] = ((k < s->N - 1) ? s->dt * s->Qd[i] : s->Qfd[i]) + s->opts.rho_primal;
+  for (int i = 0; i < m; ++i) h[n + i] = ((k < s->N - 1) ? s->dt * s->Rd[i] : 0.0) + s->opts.rho_primal;
+  return h;
+}
+
+/* value (and, if E != NULL, the Jacobian row wrt z_k) of stage row (ci, r) at knot k */
+static double pn_row(const orc_solver* s, int ci, int r, int k, const double* x, const double* u, double* E) {
+  const con_t* c = &s->con[ci];
+  int n = s->n, nz = s->nz, terminal = (k == s->N - 1);
+  double cv[64];
+  con_eval(s, c, k, x, u, cv);
+  if (E) memset(E, 0, nz * sizeof(double));
+  if (c->kind == ORC_BOX) {
+    int j = r % nz;
+    if (E) E[j] = (r < nz) ? 1.0 : -1.0;
+    return cv[r];
+  }
+  size_t blk = c->per_knot ? (size_t)(k - c->k0) : 0;
+  const double* A = c->A + blk * c->p * nz;
+  int ncol = terminal ? n : nz;
+  if (c->kind == ORC_LINEAR) {
+    if (E) for (int j = 0; j < ncol; ++j) E[j] = A[r * nz + j];
+    return cv[r];
+  }
+  /* SOC: h = ||v|| - t,  grad = (v/||v||)' A_v - A_t */
+  int q = c->p - 1;
+  double nv = 0;
+  for (int i = 0; i < q; ++i) nv += cv[i] * cv[i];
+  nv = sqrt(nv);
+  if (E) {
+    for (int j = 0; j < ncol; ++j) {
+      double g = -A[q * nz + j];
+      if (nv > 0) for (int i = 0; i < q; ++i) g += cv[i] / nv * A[i * nz + j];
+      E[j] = g;
+    }
+  }
+  return nv - cv[q];
+}
+
+/* active set + linearisation at (X, U): fills nb, nst, rcon, rrow, E, dv; returns ||d||_inf */
+static double pn_linearise(const orc_solver* s, pn_ws* w, const double* X, const double* U) {
+  int n = s->n, m = s->m, N = s->N, nz = s->nz, bm = w->bmax;
+  double tol = s->opts.active_set_tolerance_pn, viol = 0;
+  for (int k = 0; k < N; ++k) {
+    const double* x = X + (size_t)k * n;
+    const double* u = U + (size_t)(k < N - 1 ? k : 0) * m;
+    double* E = w->E + (size_t)k * bm * nz;
+    double* dv = w->dv + (size_t)k * bm;
+    int nb = 0;
+    memset(E, 0, (size_t)bm * nz * sizeof(double));
+    if (k == 0) {
+      for (int i = 0; i < n; ++i) { E[(size_t)nb * nz + i] = 1.0; dv[nb] = x[i] - s->x0[i]; nb++; }
+    }
+    int nst = 0;
+    for (int ci = 0; ci < s->ncon; ++ci) {
+      const con_t* c = &s->con[ci];
+      if (k < c->k0 || k > c->k1) continue;
+      int rows = (c->kind == ORC_SOC) ? 1 : c->p;
+      for (int r = 0; r < rows; ++r) {
+        double v = pn_row(s, ci, r, k, x, u, NULL);
+        if (!(v > -INFINITY)) continue;
+        int act = (c->kind != ORC_SOC && c->sense == ORC_EQ) || (v >= -tol);
+        if (!act) continue;
+        dv[nb] = pn_row(s, ci, r, k, x, u, E + (size_t)nb * nz);
+        w->rcon[(size_t)k * bm + nst] = ci;
+        w->rrow[(size_t)k * bm + nst] = r;
+        nb++; nst++;
+      }
+    }
+    w->nst[k] = nst;
+    if (k < N - 1) {
+      const double* A = s->A + (s->ltv ? (size_t)k * n * n : 0);
+      const double* B = s->B + (s->ltv ? (size_t)k * n * m : 0);
+      double xn[64];
+      dynamics(s, k, x, u, xn);
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) E[(size_t)nb * nz + j] = A[i + n * j];
+        for (int j = 0; j < m; ++j) E[(size_t)nb * nz + n + j] = B[i + n * j];
+        dv[nb] = xn[i] - X[(size_t)(k + 1) * n + i];
+        nb++;
+      }
+    }
+    w->nb[k] = nb;
+    for (int r = 0; r < nb; ++r) if (fabs(dv[r]) > viol) viol = fabs(dv[r]);
+  }
+  return viol;
+}
+
+/* values of the SAME rows at another trajectory (line search); returns ||d||_inf */
+static double pn_values(const orc_solver* s, const pn_ws* w, const double* X, const double* U, double* dv_out) {
+  int n = s->n, m = s->m, N = s->N, bm = w->bmax;
+  double viol = 0;
+  for (int k = 0; k < N; ++k) {
+    const double* x = X + (size_t)k * n;
+    const double* u = U + (size_t)(k < N - 1 ? k : 0) * m;
+    double* dv = dv_out + (size_t)k * bm;
+    int nb = 0;
+    if (k == 0) for (int i = 0; i < n; ++i) dv[nb++] = x[i] - s->x0[i];
+    for (int q = 0; q < w->nst[k]; ++q) dv[nb++] = pn_row(s, w->rcon[(size_t)k * bm + q], w->rrow[(size_t)k * bm + q], k, x, u, NULL);
+    if (k < N - 1) {
+      double xn[64];
+      dynamics(s, k, x, u, xn);
+      for (int i = 0; i < n; ++i) dv[nb++] = xn[i] - X[(size_t)(k + 1) * n + i];
+    }
+    for (int r = 0; r < nb; ++r) if (fabs(dv[r]) > viol) viol = fabs(dv[r]);
+  }
+  return viol;
+}
+
+/* y = S v (block tridiagonal, applied through D and H^-1): t_k = H_k^-1 (E_k' v_k - [defect part of v_{k-1}]_x),
+ * y_k = E_k t_k - [t_{k+1}]_x on the defect rows */
+static void pn_apply_S(const orc_solver* s, const pn_ws* w, const double* v, double* y, double* tz /* [N][nz] */) {
+  int n = s->n, N = s->N, nz = s->nz, bm = w->bmax;
+  for (int k = 0; k < N; ++k) {
+    const double* E = w->E + (size_t)k * bm * nz;
+    double* t = tz + (size_t)k * nz;
+    for (int j = 0; j < nz; ++j) {
+      double acc = 0;
+      for (int r = 0; r < w->nb[k]; ++r) acc += E[(size_t)r * nz + j] * v[(size_t)k * bm + r];
+      t[j] = acc;
+    }
+    if (k > 0) {
+      int off = w->nb[k - 1] - n;  /* defect rows of block k-1 are its last n rows */
+      for (int i = 0; i < n; ++i) t[i] -= v[(size_t)(k - 1) * bm + off + i];
+    }
+    for (int j = 0; j < nz; ++j) t[j] *= w->hinv[(size_t)k * nz + j];
+  }
+  for (int k = 0; k < N; ++k) {
+    const double* E = w->E + (size_t)k * bm * nz;
+    for (int r = 0; r < w->nb[k]; ++r) {
+      double acc = 0;
+      for (int j = 0; j < nz; ++j) acc += E[(size_t)r * nz + j] * tz[(size_t)k * nz + j];
+      y[(size_t)k * bm + r] = acc;
+    }
+    if (k < N - 1) {
+      int off = w->nb[k] - n;
+      for (int i = 0; i < n; ++i) y[(size_t)k * bm + off + i] -= tz[(size_t)(k + 1) * nz + i];
+    }
+  }
+}
+
+/* S + rho_chol I = L L', block by block.  Returns 0 on success. */
+static int pn_factor(const orc_solver* s, pn_ws* w) {
+  int n = s->n, N = s->N, nz = s->nz, bm = w->bmax;
+  double rho = s->opts.rho_chol;
+  for (int k = 0; k < N; ++k) {
+    int nb = w->nb[k];
+    const double* E = w->E + (size_t)k * bm * nz;
+    double* Ld = w->Ld + (size_t)k * bm * bm;
+    double* Lo = w->Lo + (size_t)k * bm * bm;
+    /* S_kk = E H^-1 E' (+ H_x,k+1^-1 on the defect rows) + rho I */
+    for (int r = 0; r < nb; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double acc = 0;
+        for (int j = 0; j < nz; ++j) acc += E[(size_t)r * nz + j] * w->hinv[(size_t)k * nz + j] * E[(size_t)c * nz + j];
+        Ld[(size_t)r * bm + c] = acc;
+      }
+    if (k < N - 1) {
+      int off = nb - n;
+      for (int i = 0; i < n; ++i) Ld[(size_t)(off + i) * bm + off + i] += w->hinv[(size_t)(k + 1) * nz + i];
+    }
+    for (int r = 0; r < nb; ++r) Ld[(size_t)r * bm + r] += rho;
+    if (k > 0) {
+      /* S_{k,k-1}[r][c]: c a defect row i of block k-1:  -E_k[r][i] / h_k[i];  L_{k,k-1} = S_{k,k-1} L_{k-1,k-1}^-T */
+      int pb = w->nb[k - 1], poff = pb - n;
+      const double* Lp = w->Ld + (size_t)(k - 1) * bm * bm;
+      for (int r = 0; r < nb; ++r) {
+        for (int c = 0; c < pb; ++c) {
+          double v = (c >= poff) ? -E[(size_t)r * nz + (c - poff)] * w->hinv[(size_t)k * nz + (c - poff)] : 0.0;
+          for (int q = 0; q < c; ++q) v -= Lo[(size_t)r * bm + q] * Lp[(size_t)c * bm + q];
+          Lo[(size_t)r * bm + c] = v / Lp[(size_t)c * bm + c];
+        }
+      }
+      for (int r = 0; r < nb; ++r)
+        for (int c = 0; c <= r; ++c) {
+          double acc = 0;
+          for (int q = 0; q < pb; ++q) acc += Lo[(size_t)r * bm + q] * Lo[(size_t)c * bm + q];
+          Ld[(size_t)r * bm + c] -= acc;
+        }
+    }
+    for (int c = 0; c < nb; ++c) {  /* Cholesky of the block, in place (lower) */
+      double dd = Ld[(size_t)c * bm + c];
+      for (int q = 0; q < c; ++q) dd -= Ld[(size_t)c * bm + q] * Ld[(size_t)c * bm + q];
+      if (!(dd > 0.0)) return 1;
+      dd = sqrt(dd);
+      Ld[(size_t)c * bm + c] = dd;
+      for (int r = c + 1; r < nb; ++r) {
+        double v = Ld[(size_t)r * bm + c];
+        for (int q = 0; q < c; ++q) v -= Ld[(size_t)r * bm + q] * Ld[(size_t)c * bm + q];
+        Ld[(size_t)r * bm + c] = v / dd;
+      }
+    }
+  }
+  return 0;
+}
+
+/* x = (L L')^-1 b */
+static void pn_chol_solve(const orc_solver* s, const pn_ws* w, const double* b, double* x) {
+  int N = s->N, bm = w->bmax;
+  for (int k = 0; k < N; ++k) {  /* forward */
+    int nb = w->nb[k];
+    const double* Ld = w->Ld + (size_t)k * bm * bm;
+    const double* Lo = w->Lo + (size_t)k * bm * bm;
+    for (int r = 0; r < nb; ++r) {
+      double v = b[(size_t)k * bm + r];
+      if (k > 0) for (int q = 0; q < w->nb[k - 1]; ++q) v -= Lo[(size_t)r * bm + q] * x[(size_t)(k - 1) * bm + q];
+      for (int q = 0; q < r; ++q) v -= Ld[(size_t)r * bm + q] * x[(size_t)k * bm + q];
+      x[(size_t)k * bm + r] = v / Ld[(size_t)r * bm + r];
+    }
+  }
+  for (int k = N - 1; k >= 0; --k) {  /* backward */
+    int nb = w->nb[k];
+    const double* Ld = w->Ld + (size_t)k * bm * bm;
+    for (int r = nb - 1; r >= 0; --r) {
+      double v = x[(size_t)k * bm + r];
+      if (k < N - 1) {
+        const double* Ln = w->Lo + (size_t)(k + 1) * bm * bm;
+        for (int q = 0; q < w->nb[k + 1]; ++q) v -= Ln[(size_t)q * bm + r] * x[(size_t)(k + 1) * bm + q];
+      }
+      for (int q = r + 1; q < nb; ++q) v -= Ld[(size_t)q * bm + r] * x[(size_t)k * bm + q];
+      x[(size_t)k * bm + r] = v / Ld[(size_t)r * bm + r];
+    }
+  }
+}
+
+static int projected_newton(orc_solver* s, double* viol_out) {
+  const orc_opts* o = &s->opts;
+  int n = s->n, m = s->m, N = s->N, nz = s->nz;
+  int pm = 0;
+  for (int ci = 0; ci < s->ncon; ++ci) pm += (s->con[ci].kind == ORC_SOC) ? 1 : s->con[ci].p;
+  pn_ws w;
+  w.bmax = 2 * n + pm;
+  int bm = w.bmax;
+  w.nb = (int*)calloc(N, sizeof(int)); w.nst = (int*)calloc(N, sizeof(int));
+  w.rcon = (int*)calloc((size_t)N * bm, sizeof(int)); w.rrow = (int*)calloc((size_t)N * bm, sizeof(int));
+  w.E = dalloc((size_t)N * bm * nz); w.dv = dalloc((size_t)N * bm);
+  w.Ld = dalloc((size_t)N * bm * bm); w.Lo = dalloc((size_t)N * bm * bm); w.hinv = dalloc((size_t)N * nz);
+  double *lam = dalloc((size_t)N * bm), *res = dalloc((size_t)N * bm), *cor = dalloc((size_t)N * bm), *Sv = dalloc((size_t)N * bm);
+  double *tz = dalloc((size_t)N * nz), *dz = dalloc((size_t)N * nz), *dtrial = dalloc((size_t)N * bm);
+  for (int k = 0; k < N; ++k) {
+    double h[128];
+    pn_hdiag(s, k, h);
+    for (int j = 0; j < nz; ++j) w.hinv[(size_t)k * nz + j] = 1.0 / h[j];
+  }
+  double viol = pn_linearise(s, &w, s->X, s->U);
+  int rc = 0;
+  for (int outer = 0; outer <= 10 && viol > o->constraint_tolerance; ++outer) {   /* projection_solve! */
+    if (outer > 0) viol = pn_linearise(s, &w, s->X, s->U);
+    if (pn_factor(s, &w)) { rc = 1; break; }
+    double viol_prev = viol;
+    for (int refine = 0; refine < 10; ++refine) {                                   /* _projection_solve! */
+      /* reg_solve: S lam = d with the factors of S + rho I, refined against S (tol 1e-8, at most 25 rounds) */
+      pn_chol_solve(s, &w, w.dv, lam);
+      for (int it = 0; it < 25; ++it) {
+        pn_apply_S(s, &w, lam, Sv, tz);
+        double rn = 0;
+        for (int k = 0; k < N; ++k)
+          for (int r = 0; r < w.nb[k]; ++r) {
+            double e = w.dv[(size_t)k * bm + r] - Sv[(size_t)k * bm + r];
+            res[(size_t)k * bm + r] = e;
+            if (fabs(e) > rn) rn = fabs(e);
+          }
+        if (rn < 1e-8) break;
+        pn_chol_solve(s, &w, res, cor);
+        for (int k = 0; k < N; ++k) for (int r = 0; r < w.nb[k]; ++r) lam[(size_t)k * bm + r] += cor[(size_t)k * bm + r];
+      }
+      /* dz = -H^-1 D' lam */
+      pn_apply_S(s, &w, lam, Sv, tz);
+      for (size_t i = 0; i < (size_t)N * nz; ++i) dz[i] = -tz[i];
+      /* _projection_linesearch! */
+      double alpha = 1.0, v_new = viol;
+      for (int ls = 0;; ++ls) {
+        for (int k = 0; k < N; ++k) {
+          for (int i = 0; i < n; ++i) s->Xb[(size_t)k * n + i] = s->X[(size_t)k * n + i] + alpha * dz[(size_t)k * nz + i];
+          if (k < N - 1) for (int i = 0; i < m; ++i) s->Ub[(size_t)k * m + i] = s->U[(size_t)k * m + i] + alpha * dz[(size_t)k * nz + n + i];
+        }
+        v_new = pn_values(s, &w, s->Xb, s->Ub, dtrial);
+        if (v_new < viol || ls >= 10) break;
+        alpha *= 0.5;
+      }
+      memcpy(s->X, s->Xb, (size_t)N * n * sizeof(double));
+      memcpy(s->U, s->Ub, (size_t)(N - 1) * m * sizeof(double));
+      memcpy(w.dv, dtrial, (size_t)N * bm * sizeof(double));
+      viol = v_new;
+      double rate = log10(viol) / log10(viol_prev);
+      viol_prev = viol;
+      if (viol < o->constraint_tolerance) break;
+      if (rate < o->r_threshold) break;
+    }
+  }
+  *viol_out = viol;
+  free(w.nb); free(w.nst); free(w.rcon); free(w.rrow); free(w.E); free(w.dv); free(w.Ld); free(w.Lo); free(w.hinv);
+  free(lam); free(res); free(cor); free(Sv); free(tz); free(dz); free(dtrial);
+  return rc;
+}
+
+/* objective (no AL terms) and violation of the problem's constraints at (X, U) as they are (not rolled out) */
+static double objective_and_violation(orc_solver* s, double* cmax) {
+  int n = s->n, m = s->m, N = s->N;
+  double J = 0, vmax = 0;
+  for (int k = 0; k < N; ++k) {
+    const double* x = s->X + (size_t)k * n;
+    double l = 0;
+    const double* Qd = (k < N - 1) ? s->Qd : s->Qfd;
+    for (int i = 0; i < n; ++i) { double e = x[i] - s->Xref[(size_t)k * n + i]; l += 0.5 * Qd[i] * e * e; }
+    if (k < N - 1) for (int i = 0; i < m; ++i) { double e = s->U[(size_t)k * m + i] - s->Uref[(size_t)k * m + i]; l += 0.5 * s->Rd[i] * e * e; }
+    J += (k < N - 1) ? l * s->dt : l;
+  }
+  for (int ci = 0; ci < s->ncon; ++ci) {
+    con_t* c = &s->con[ci];
+    for (int k = c->k0; k <= c->k1; ++k) {
+      size_t off = (size_t)(k - c->k0) * c->p;
+      con_eval(s, c, k, s->X + (size_t)k * n, s->U + (size_t)(k < N - 1 ? k : 0) * m, c->c + off);
+      double v = con_violation(c, c->c + off);
+      if (v > vmax) vmax = v;
+    }
+  }
+  *cmax = vmax;
+  return J;
+}
+
 /* solve!(::ALTROSolver) -> solve!(::AugmentedLagrangianSolver)  (P2).
  * projected_newton is false in every MPC benchmark of the reference
  * (run_random_linear.jl:48) and is not restated. */
 void orc_solve(orc_solver* s) {
+  orc_opts opts_al = s->opts;         /* solve!(::ALTROSolver): with the polish on, the AL stage only has to reach its tolerance */
+  const orc_opts user = s->opts;
+  if (user.projected_newton) {
+    if (user.projected_newton_tolerance >= 0) opts_al.constraint_tolerance = user.projected_newton_tolerance;
+    else { opts_al.constraint_tolerance = 0; opts_al.kickout_max_penalty = 1; }
+  }
+  s->opts = opts_al;
   const orc_opts* o = &s->opts;
   orc_stats* st = &s->stats;
   memset(st, 0, sizeof(*st));
@@ -837,6 +1199,7 @@ void orc_solve(orc_solver* s) {
     J = ilqr_solve(s, o->cost_tolerance, o->gradient_tolerance, &cmax);
     st->cost = J; st->c_max = 0;
     if (st->status == ORC_UNSOLVED) st->status = ORC_SOLVE_SUCCEEDED;
+    s->opts = user;
     return;
   }
   for (int j = 0; j < o->iterations_outer; ++j) {
@@ -854,7 +1217,16 @@ void orc_solve(orc_solver* s) {
     dual_penalty_update(s);
   }
   st->cost = J; st->c_max = cmax;
-  if (st->status <= ORC_SOLVE_SUCCEEDED && cmax < o->constraint_tolerance) st->status = ORC_SOLVE_SUCCEEDED;
+  s->opts = user;
+  if (st->status <= ORC_SOLVE_SUCCEEDED && user.projected_newton && cmax > user.constraint_tolerance) {
+    double dviol;
+    st->pn_ran = 1;
+    st->pn_failed = projected_newton(s, &dviol);
+    st->pn_residual = dviol;                  /* ||d||_inf of the active rows, the initial condition and the dynamics defects */
+    st->cost = objective_and_violation(s, &cmax);
+    st->c_max = cmax;
+  }
+  if (st->status <= ORC_SOLVE_SUCCEEDED && cmax < user.constraint_tolerance) st->status = ORC_SOLVE_SUCCEEDED;
 }
 
 /* RD.shift_fill!(Z) (P11) and Altro.shift_fill!(conSet) (P10): shift by one knot, repeat the

@@ -81,6 +81,16 @@ typedef struct {
   int soc_second_order;                /* 1: add the projection-curvature term to the SOC Hessian */
   int kickout_max_penalty;             /* 0 (Altro.jl's default): the AL loop does NOT stop when the penalty reaches
                                           penalty_max, it goes on updating duals at the cap; 1: it stops there */
+  /* projected-Newton polish (ALTRO, IROS 2019, Algorithm 4; Altro.jl solve!(::ALTROSolver)).  0 here: Altro.jl's own
+   * default is true, but every script of the reference on this path sets it false; the one that does not
+   * (old/altro_cold_solve.jl:79-86) ends with the polish skipped.  PARITY UNPINNED: nothing in the reference records a
+   * trajectory the polish produced. */
+  int projected_newton;
+  double projected_newton_tolerance;   /* 1e-3: the AL stage stops at this violation, then the polish runs */
+  double active_set_tolerance_pn;      /* 1e-3: an inequality row with c >= -tol is in the polish's active set */
+  double rho_chol;                     /* 1e-2: S + rho I is what is factored (reg_solve refines against S) */
+  double rho_primal;                   /* 1e-8: added to the (diagonal) cost Hessian */
+  double r_threshold;                  /* 1.1: refinement stops when log(viol)/log(viol_prev) falls below it */
 } orc_opts;
 
 #define ORC_TRACE_MAX 256
@@ -100,6 +110,9 @@ typedef struct {
   /* per outer iteration */
   double c_max_outer[64];
   double penalty_max_outer[64];
+  /* projected-Newton polish */
+  int pn_ran, pn_failed;     /* the polish ran (AL ended above constraint_tolerance); a block of S was not positive definite */
+  double pn_residual;        /* its final ||d||_inf (active rows, initial condition, dynamics defects) */
 } orc_stats;
 
 typedef struct orc_solver orc_solver;

@@ -31,7 +31,8 @@ class Opts(C.Structure):
         [(k, C.c_int) for k in (
             "iterations", "iterations_inner", "iterations_outer", "iterations_linesearch",
             "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order",
-            "kickout_max_penalty")]
+            "kickout_max_penalty", "projected_newton")] + \
+        [(k, C.c_double) for k in ("projected_newton_tolerance", "active_set_tolerance_pn", "rho_chol", "rho_primal", "r_threshold")]
 
 
 class Stats(C.Structure):
@@ -40,7 +41,8 @@ class Stats(C.Structure):
                 ("J", C.c_double * TRACE_MAX), ("dJ", C.c_double * TRACE_MAX),
                 ("grad", C.c_double * TRACE_MAX), ("alpha", C.c_double * TRACE_MAX),
                 ("cmax_it", C.c_double * TRACE_MAX),
-                ("c_max_outer", C.c_double * 64), ("penalty_max_outer", C.c_double * 64)]
+                ("c_max_outer", C.c_double * 64), ("penalty_max_outer", C.c_double * 64),
+                ("pn_ran", C.c_int), ("pn_failed", C.c_int), ("pn_residual", C.c_double)]
 
 
 def build(force=False):
