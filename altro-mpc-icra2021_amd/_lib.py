@@ -34,7 +34,7 @@ EXPORTS = [
     "altro_mpc_set_noise_model", "altro_mpc_set_shift", "altro_mpc_set_track", "altro_mpc_set_noise",
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
     "altro_mpc_prepare_async", "altro_batch_benchmark_solve", "altro_mpc_set_dynamics_track",
-    "altro_batch_get_confirm_counter", "altro_batch_get_reuse_counter",
+    "altro_batch_get_confirm_counter", "altro_batch_get_reuse_counter", "altro_batch_get_polish_stats",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -52,7 +52,9 @@ class Opts(C.Structure):
         "bp_reg_initial", "bp_reg_increase_factor", "bp_reg_max", "bp_reg_min", "bp_reg_fp")] + \
         [(k, C.c_int32) for k in (
             "iterations", "iterations_inner", "iterations_outer", "iterations_linesearch",
-            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order", "strict", "kickout_max_penalty")]
+            "dJ_counter_limit", "reset_duals", "reset_penalties", "bp_reg", "soc_second_order", "strict", "kickout_max_penalty",
+            "projected_newton")] + \
+        [(k, C.c_double) for k in ("projected_newton_tolerance", "active_set_tolerance_pn", "rho_chol", "rho_primal", "r_threshold")]
 
 
 class AltroError(RuntimeError):
@@ -137,6 +139,7 @@ def lib():
     L.altro_mpc_prepare_async.argtypes = [H, C.c_int32]
     L.altro_batch_get_confirm_counter.argtypes = [H, C.POINTER(C.c_int64)]
     L.altro_batch_get_reuse_counter.argtypes = [H, C.POINTER(C.c_int64)]
+    L.altro_batch_get_polish_stats.argtypes = [H, ip, ip, dp]
     L.altro_mpc_set_dynamics_track.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32, C.c_int32]
     L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     for name in EXPORTS:

@@ -47,13 +47,8 @@ def SolverOptions(**kw):
     if rc:
         raise AltroError(rc, "altro_default_opts")
     for k, v in kw.items():
-        if k in ("projected_newton", "verbose", "show_summary", "static_bp", "save_S",
-                 "projected_newton_tolerance"):
-            # accepted for source compatibility: projected_newton is false in every MPC run of
-            # the reference (run_random_linear.jl:48) and is not built; the others only affect
-            # printing or Julia-side memory layout.
-            if k == "projected_newton" and v:
-                raise AltroError(_lib.ERR_UNSUPPORTED, "projected_newton=true is not built")
+        if k in ("verbose", "show_summary", "static_bp", "save_S"):
+            # accepted for source compatibility: they only affect printing or Julia-side memory layout
             continue
         if not hasattr(o, k):
             raise KeyError(f"unknown SolverOptions field {k}")
@@ -404,6 +399,16 @@ def confirm_counter(solver):
     a = np.zeros(solver.B, dtype=np.int64)
     solver._chk(solver._L.altro_batch_get_confirm_counter(solver.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
     return a
+
+
+def polish_stats(solver):
+    """(ran, failed, residual) of the projected-Newton polish of the last solve, per instance
+    (altro_batch_get_polish_stats; all zero with projected_newton = false)."""
+    ran, failed = np.zeros(solver.B, dtype=np.int32), np.zeros(solver.B, dtype=np.int32)
+    res = np.zeros(solver.B)
+    ip = C.POINTER(C.c_int32)
+    solver._chk(solver._L.altro_batch_get_polish_stats(solver.h, ran.ctypes.data_as(ip), failed.ctypes.data_as(ip), _p(res)))
+    return ran, failed, res
 
 
 def reuse_counter(solver):

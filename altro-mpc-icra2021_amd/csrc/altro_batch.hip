@@ -15,6 +15,7 @@
 
 #include "../../include/altro_batch.h"
 #include "launch_ring.h"
+#include "pn_polish.h"
 #include "solve_dpp16.h"
 #include "wide_backend.h"
 
@@ -45,6 +46,12 @@ struct altro_handle {
          *KD = nullptr, *Qz = nullptr, *Dff = nullptr, *kmu = nullptr;
   altro::AHash* ahash = nullptr;  // [Bp][16] active set of the backward pass behind the gains in KD (gain reuse, solve_dpp16.h)
   long long* n_fo = nullptr;
+  // projected-Newton polish (pn_polish.h): per-instance results and the workspace, allocated by the first solve that asks for it
+  int *pn_ran = nullptr, *pn_failed = nullptr;
+  double* pn_res = nullptr;
+  double *pnE = nullptr, *pndv = nullptr, *pnLd = nullptr, *pnLo = nullptr, *pnvec = nullptr, *pntz = nullptr;
+  int *pnnb = nullptr, *pnnst = nullptr, *pnrinfo = nullptr;
+  int pn_bm = 0;
   double *noise = nullptr, *noise_w = nullptr;
   int* noise_grp = nullptr;
   int noise_mode = 0;
@@ -414,6 +421,10 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
   p.n_gconf = h->n_gconf; p.dzero = h->dzero;
   p.o = h->o;
+  if (h->o.projected_newton) {  // solve!(::ALTROSolver): the AL stage only has to reach the polish's tolerance
+    if (h->o.projected_newton_tolerance >= 0) p.o.constraint_tolerance = h->o.projected_newton_tolerance;
+    else { p.o.constraint_tolerance = 0.0; p.o.kickout_max_penalty = 1; }
+  }
   p.perm = nullptr;
   // fused MPC launches of box-constrained problems: group the instances by how many of the launch's steps will need
   // backward passes (see k_group_score); everything else runs in instance order
@@ -527,6 +538,12 @@ int32_t altro_default_opts(altro_opts* o) {
     o->soc_second_order = 1;
     o->strict = 0;
     o->kickout_max_penalty = 0;
+    o->projected_newton = 0;
+    o->projected_newton_tolerance = 1e-3;
+    o->active_set_tolerance_pn = 1e-3;
+    o->rho_chol = 1e-2;
+    o->rho_primal = 1e-8;
+    o->r_threshold = 1.1;
     return ALTRO_OK;
   });
 }
@@ -564,6 +581,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       } wo{hw, wb};
       altro_opts o0;
       if (opts) o0 = *opts; else altro_default_opts(&o0);
+      if (o0.projected_newton) { g_create_err = "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)"; return ALTRO_ERR_UNSUPPORTED; }
       hw->d = *dims;
       hw->o = o0;
       hw->device = device;
@@ -661,6 +679,12 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemsetAsync(h->ahash, 0, row * sizeof(altro::AHash), h->stream));
     CCHK(hipMalloc(&h->kmu, Bp * sizeof(double)));
     CCHK(hipMalloc(&h->n_fo, Bp * sizeof(long long)));
+    CCHK(hipMalloc(&h->pn_ran, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->pn_failed, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->pn_res, Bp * sizeof(double)));
+    CCHK(hipMemsetAsync(h->pn_ran, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->pn_failed, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->pn_res, 0, Bp * sizeof(double), h->stream));
     CCHK(hipMemsetAsync(h->n_fo, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->Qz, 0, (N + 1) * row * sizeof(double), h->stream));
     CCHK(hipMalloc(&h->cur, Bp * sizeof(int)));
@@ -734,7 +758,9 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
                    (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz,
-                   (void**)&h->Dff, (void**)&h->ahash, (void**)&h->kmu, (void**)&h->n_fo, (void**)&h->perm, (void**)&h->gscore};
+                   (void**)&h->Dff, (void**)&h->ahash, (void**)&h->kmu, (void**)&h->n_fo, (void**)&h->perm, (void**)&h->gscore,
+                   (void**)&h->pn_ran, (void**)&h->pn_failed, (void**)&h->pn_res, (void**)&h->pnE, (void**)&h->pndv, (void**)&h->pnLd, (void**)&h->pnLo,
+                   (void**)&h->pnvec, (void**)&h->pntz, (void**)&h->pnnb, (void**)&h->pnnst, (void**)&h->pnrinfo};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
   h->stage_bytes = 0;
@@ -1129,12 +1155,53 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
 
 int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
   return guard(h, [&]() -> int32_t {
-    if (h && h->wide && o) { h->wide->o = *o; h->wide->gains_valid = false; h->o = *o; return ALTRO_OK; }
+    if (h && h->wide && o) {
+      if (o->projected_newton) FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)");
+      h->wide->o = *o; h->wide->gains_valid = false; h->o = *o; return ALTRO_OK;
+    }
     if (!h || !o) return ALTRO_ERR_INVALID_ARG;
     h->o = *o;
     HIPCHK(h, hipSetDevice(h->device));
     return drop_gains(h);
   });
+}
+
+// solve!(::ProjectedNewtonSolver) after the AL kernel of a plain solve (altro_opts.projected_newton)
+static int launch_polish(altro_handle* h) {
+  const size_t Bp = h->Bp, N = h->d.N;
+  int nbounded = 0;
+  for (int j = 0; j < LW; ++j) nbounded += h->bslot_h[j] >= 0 ? 1 : 0;
+  const int bm = 2 * h->d.n + (h->box_k1 >= h->box_k0 ? 2 * nbounded : 0) + (h->ncrows > 0 ? LW : 0);
+  if (bm > altro_pn::BMAX) FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton: more rows per knot than pn_polish.h holds");
+  if (h->pn_bm != bm || !h->pnE) {
+    void** ws[] = {(void**)&h->pnE, (void**)&h->pndv, (void**)&h->pnLd, (void**)&h->pnLo, (void**)&h->pnvec, (void**)&h->pntz,
+                   (void**)&h->pnnb, (void**)&h->pnnst, (void**)&h->pnrinfo};
+    for (void** q : ws) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
+    HIPCHK(h, hipMalloc(&h->pnE, Bp * N * bm * LW * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pndv, Bp * N * bm * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pnLd, Bp * N * bm * bm * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pnLo, Bp * N * bm * bm * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pnvec, Bp * 6 * N * bm * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pntz, Bp * N * LW * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pnnb, Bp * N * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->pnnst, Bp * N * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->pnrinfo, Bp * N * bm * sizeof(int)));
+    h->pn_bm = bm;
+  }
+  altro_pn::PnParams q{};
+  q.B = h->d.batch; q.Bp = h->Bp; q.N = h->d.N; q.n = h->d.n; q.m = h->d.m; q.bm = bm;
+  q.box_k0 = h->box_k0; q.box_k1 = h->box_k1; q.ncrows = h->ncrows;
+  q.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u;
+  q.Grow = h->Grow; q.fvec = h->fvec; q.wd = h->wd; q.wf = h->wf; q.zmin = h->zmin; q.zmax = h->zmax; q.x0 = h->x0;
+  q.Acon = h->Acon; q.bcon = h->bcon; q.cmeta = h->cmeta;
+  q.Z = h->Z; q.Zref = h->Zref; q.kref = h->kref; q.cur = h->cur; q.status = h->status; q.cost = h->cost; q.cmax = h->cmax;
+  q.pn_ran = h->pn_ran; q.pn_failed = h->pn_failed; q.pn_res = h->pn_res;
+  q.E = h->pnE; q.dv = h->pndv; q.Ld = h->pnLd; q.Lo = h->pnLo; q.vec = h->pnvec; q.tz = h->pntz;
+  q.nb = h->pnnb; q.nst = h->pnnst; q.rinfo = h->pnrinfo;
+  q.o = h->o;
+  hipLaunchKernelGGL(altro_pn::pn_kernel, dim3(h->d.batch), dim3(64), 0, h->stream, q);
+  HIPCHK(h, hipGetLastError());
+  return ALTRO_OK;
 }
 
 static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
@@ -1149,8 +1216,12 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   HIPCHK(h, h->ring.next(&h0, &h1));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   HIPCHK(h, hipEventRecord(h0, h->stream));
+  if (h->o.projected_newton && nsteps > 0)
+    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
+                                   "(every MPC script of the reference sets projected_newton = false)");
   rc = launch_solve(h, first_step, nsteps);
   if (rc) return rc;
+  if (h->o.projected_newton && (rc = launch_polish(h))) return rc;
   HIPCHK(h, hipEventRecord(h1, h->stream));
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -1406,6 +1477,31 @@ int32_t altro_batch_get_reuse_counter(altro_handle* h, int64_t* reused) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(reused, h->n_fo, (size_t)h->d.batch * sizeof(long long), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
+}
+
+int32_t altro_batch_get_polish_stats(altro_handle* h, int32_t* ran, int32_t* failed, double* residual) {
+  return guard(h, [&]() -> int32_t {
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    const size_t B = h->d.batch;
+    if (h->wide) {  // the one-wave-per-instance backend has no polish: nothing ran
+      if (ran) std::memset(ran, 0, B * sizeof(int32_t));
+      if (failed) std::memset(failed, 0, B * sizeof(int32_t));
+      if (residual) std::memset(residual, 0, B * sizeof(double));
+      return ALTRO_OK;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->o.projected_newton) {
+      HIPCHK(h, hipMemsetAsync(h->pn_ran, 0, h->Bp * sizeof(int), h->stream));
+      HIPCHK(h, hipMemsetAsync(h->pn_failed, 0, h->Bp * sizeof(int), h->stream));
+      HIPCHK(h, hipMemsetAsync(h->pn_res, 0, h->Bp * sizeof(double), h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (ran) HIPCHK(h, hipMemcpy(ran, h->pn_ran, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (failed) HIPCHK(h, hipMemcpy(failed, h->pn_failed, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (residual) HIPCHK(h, hipMemcpy(residual, h->pn_res, B * sizeof(double), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   });
 }

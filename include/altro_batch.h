@@ -129,6 +129,18 @@ typedef struct altro_opts {
    * iterations_outer runs out (MAX_ITERATIONS_OUTER); 1 ends the solve there (status UNSOLVED if the violation is
    * still above the tolerance). */
   int32_t kickout_max_penalty;
+  /* Projected-Newton polish (Altro.jl solve!(::ALTROSolver): AL stage to projected_newton_tolerance, then
+   * solve!(::ProjectedNewtonSolver) if the violation is still above constraint_tolerance; ALTRO, IROS 2019, Algorithm 4).
+   * altro_default_opts() gives 0: Altro.jl's own default is true, but every script of the reference on this path sets
+   * projected_newton = false (eleven occurrences), and the ccall shim passes the Julia-side value explicitly.  1: plain
+   * solves (altro_batch_solve) of the 16-lane backend run csrc/pn_polish.h after the AL kernel; the device-resident MPC
+   * loop and the one-wave-per-instance backend refuse it.  PARITY UNPINNED: the reference stores no polished trajectory. */
+  int32_t projected_newton;
+  double projected_newton_tolerance;   /* 1e-3 */
+  double active_set_tolerance_pn;      /* 1e-3: inequality rows with c >= -tol join the polish's active set */
+  double rho_chol;                     /* 1e-2: S + rho I is factored, the solve is refined against S */
+  double rho_primal;                   /* 1e-8: added to the diagonal cost Hessian */
+  double r_threshold;                  /* 1.1 */
 } altro_opts;
 
 #define ALTRO_TRACE_LEN 16 /* per-instance trace depth kept on device */
@@ -267,6 +279,11 @@ int32_t altro_batch_get_confirm_counter(altro_handle* h, int64_t* confirmed);
  * then its rollout as usual; counted in `iterations`, not in `backward_passes` (altro_opts.strict = 1: never taken).
  * Every setter the gains depend on (dynamics, cost, constraints, options) drops them. */
 int32_t altro_batch_get_reuse_counter(altro_handle* h, int64_t* reused);
+/* Projected-Newton polish of the last solve, per instance (arrays of `batch`; any pointer may be NULL): ran (the AL
+ * stage ended SOLVE_SUCCEEDED-or-unsolved above constraint_tolerance), failed (a block of D H^-1 D' + rho I was not
+ * positive definite), residual (final max |d| over the active rows, the initial condition and the dynamics defects).
+ * All zero when altro_opts.projected_newton = 0. */
+int32_t altro_batch_get_polish_stats(altro_handle* h, int32_t* ran, int32_t* failed, double* residual);
 /* Diagnostic (16-lane kernels): 16 int64 per wave (4 instances) of the last solve launch.  [0] s_memtime ticks in
  * total; [7] backward passes the wave ran in the lone-row form (one instance over the four DPP rows).  The
  * -DALTRO_PHASE_STAMPS build also fills ticks per phase -- [1] four-row backward passes, [2] closed-loop rollouts,

@@ -1597,3 +1597,55 @@ def test_error_paths():
     with pytest.raises(altro.AltroError) as e:
         altro.ALTROSolver(prob)
     assert e.value.code == altro._lib.ERR_UNSUPPORTED
+
+
+def test_projected_newton_polish_matches_oracle(oracle):
+    """SURVEY 8 f4 (parity with Altro.jl unpinned; see tests/test_oracle_cones.py): altro_opts.projected_newton = 1 --
+    the AL kernel stops at projected_newton_tolerance, then csrc/pn_polish.h projects the trajectory onto the active
+    constraints and the dynamics.  Against the oracle's polish on (a) a box-constrained LQ batch with saturating
+    controls and (b) the grasp problem (cones, per-knot equalities and inequalities, goal): same AL stage, same
+    decision to polish, the polished trajectories within 1e-6, constraints and dynamics to the polish tolerance."""
+    B = 5
+    pb = altro.problems.gen_random_linear_batch(B, steps=1, seed=81)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    rng = np.random.default_rng(3)
+    prob.x0 = prob.x0 + np.array([25.0, 25.0, 0.1, 12.0, 25.0])[:, None] + rng.standard_normal(prob.x0.shape)
+    opts = dict(REF_OPTS, constraint_tolerance=1e-8, projected_newton=1)
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**opts))
+    altro.solve(sv)
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    ran, failed, res = altro.polish_stats(sv)
+    assert ran.sum() >= 3 and not failed.any()
+    for b in range(B):
+        o = make_oracle(oracle, pb, b, opts=opts)
+        o.set_initial_state(prob.x0[b])
+        so = o.solve()
+        assert int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations and int(ran[b]) == so.pn_ran
+        assert abs(st.cost[b] - so.cost) <= RTOL * max(1.0, abs(so.cost)) and st.c_max[b] < 1e-8
+        assert rel_err(X[b], o.states()) <= RTOL and rel_err(U[b], o.controls()) <= RTOL
+        if ran[b]:
+            assert np.abs(X[b, :-1] @ pb.A[b].T + U[b] @ pb.Bm[b].T - X[b, 1:]).max() < 1e-8 and np.abs(U[b]).max() <= pb.u_bnd + 1e-8
+    # the grasp problem: AL stage to a loose 1e-2, polish to 1e-6
+    gp = P.gen_grasp_problem(N=31, tf=3.0)
+    gopts = dict(cost_tolerance_intermediate=1e-5, penalty_initial=1.0, penalty_scaling=10.0, constraint_tolerance=1e-6,
+                 projected_newton=1, projected_newton_tolerance=1e-2)
+    x0 = np.tile(gp.x0, (3, 1))
+    x0[1:, 1:3] += 0.1 * rng.standard_normal((2, 2))
+    sg = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0), altro.SolverOptions(**gopts))
+    altro.solve(sg)
+    st, X, U = altro.stats(sg), altro.states(sg), altro.controls(sg)
+    ran, failed, res = altro.polish_stats(sg)
+    assert ran.all() and not failed.any() and res.max() < 1e-6
+    for b in range(3):
+        o = rocket_oracle(oracle, gp, x0[b], gopts)
+        so = o.solve()
+        assert so.pn_ran == 1 and int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations
+        assert st.c_max[b] < 1e-6 and abs(st.cost[b] - so.cost) <= 1e-5 * max(1.0, abs(so.cost))
+        assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-5
+    # the device-resident MPC loop and the one-wave-per-instance backend refuse the option
+    with pytest.raises(altro.AltroError):
+        mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(**opts))
+        mp.initial_solve()
+        mp.step(0)
+    with pytest.raises(altro.AltroError):
+        altro.ALTROSolver(altro.mpc.gen_tracking_problem(altro.problems.gen_random_linear_batch(2, n=20, m=4, N=11, steps=1)), altro.SolverOptions(**opts))
