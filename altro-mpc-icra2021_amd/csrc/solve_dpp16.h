@@ -848,6 +848,22 @@ struct Solver {
     return acc / (double)(N - 1);
   }
 
+  // Lone streaming sweeps (conic kernels).  The sweeps below have no recurrence over the knots, so when only ONE row of
+  // the wave needs one -- the stragglers of a conic launch walk thousands of line-searched iterations after their
+  // wave-mates are done (tools/gpu_rocket_tail.py: 7050 iterations of one instance in 20 steps against a mean of 750) --
+  // the wave's four DPP rows take every fourth chunk of knots of that one instance (the caller points inst / rowoff / rs
+  // of all lanes at it) and the partial results are combined across the rows.
+  static __device__ __forceinline__ double rows_sum4(double v) {
+    double o[4];
+    rows_gather(v, o);
+    return (o[0] + o[1]) + (o[2] + o[3]);
+  }
+  static __device__ __forceinline__ double rows_max4(double v) {
+    double o[4];
+    rows_gather(v, o);
+    return fmax(fmax(o[0], o[1]), fmax(o[2], o[3]));
+  }
+
   // ---- line search on alpha < 1 without new rollouts ------------------------------------
   // Dynamics are linear/affine and the control law u + K dx + alpha d is affine, so the trial
   // trajectory is affine in alpha:  Z̄(alpha) = Z + alpha (Z̄(1) - Z)  (exact identity; alpha is a
@@ -863,8 +879,10 @@ struct Solver {
     bool limit[NA], unchanged[NA];
   };
 
+  template <bool LONE = false>
   __device__ void trial_costs(double alpha, Trials& T) {
     phase_begin();
+    const int rr = LONE ? (lane >> 4) : 0;  // lone sweep: this DPP row takes the chunks rr, rr + 4, ...
     const LaneConst lc = consts();
     const double mu = rs->mu;
     const int cur = rs->cur, kref = rs->kref;
@@ -887,9 +905,9 @@ struct Solver {
     const double dmax = P.o.dual_max;
     const bool so2 = P.o.soc_second_order != 0;
     constexpr int UN = CONES ? 2 : ALTRO_UN;  // cone tables cost registers
-    const int nch = (N + UN - 1) / UN;
+    const int nch = LONE ? (N + 4 * UN - 1) / (4 * UN) : (N + UN - 1) / UN;
     for (int c = 0; c < nch; ++c) {
-      const int k0 = c * UN;
+      const int k0 = LONE ? (4 * c + rr) * UN : c * UN;
       double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN], lcq[UN];
       ConK ckq[UN];
       sfor<0, UN>([&](auto q) {
@@ -940,24 +958,26 @@ struct Solver {
     }
     sfor<0, NA>([&](auto t) {
       constexpr int Tt = decltype(t)::value;
-      T.J[Tt] = row_sum(Jacc[Tt]);
-      T.cmax[Tt] = row_max(viol[Tt]);
-      T.limit[Tt] = row_any(lim[Tt], lane);
-      T.unchanged[Tt] = !row_any(chg[Tt], lane);
+      T.J[Tt] = LONE ? rows_sum4(row_sum(Jacc[Tt])) : row_sum(Jacc[Tt]);
+      T.cmax[Tt] = LONE ? rows_max4(row_max(viol[Tt])) : row_max(viol[Tt]);
+      T.limit[Tt] = LONE ? wave_any(lim[Tt]) : row_any(lim[Tt], lane);
+      T.unchanged[Tt] = LONE ? !wave_any(chg[Tt]) : !row_any(chg[Tt], lane);
     });
   }
 
   // Z̄ <- Z + alpha (Z̄(1) - Z) in plane cur^1, for the rows flagged `doit`
+  template <bool LONE = false>
   __device__ void interpolate(double alpha, bool doit) {
     phase_begin();
+    const int rr = LONE ? (lane >> 4) : 0;
     const int cur = rs->cur;
     const unsigned zs = plane(cur);
     const unsigned z1 = plane(cur ^ 1);
     const int N = P.N;
     constexpr int UN = ALTRO_UN;
-    const int nch = (N + UN - 1) / UN;
+    const int nch = LONE ? (N + 4 * UN - 1) / (4 * UN) : (N + UN - 1) / UN;
     for (int c = 0; c < nch; ++c) {
-      const int k0 = c * UN;
+      const int k0 = LONE ? (4 * c + rr) * UN : c * UN;
       double z[UN], zz1[UN];
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
@@ -1396,6 +1416,43 @@ struct Solver {
   static __device__ __forceinline__ double lane_gather(double v, int src_lane) {  // v of lane src_lane (ds_bpermute)
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+
+  // Lone phases: all four DPP rows take the identity of row lrow (wave-uniform) for the duration of one phase.
+  struct LoneCtx {
+    int inst;
+    unsigned rowoff;
+    RowState* rs;
+    double* sm;
+    AHash* ah;
+  };
+  __device__ __forceinline__ LoneCtx lone_enter(int lrow) {
+    LoneCtx c{inst, rowoff, rs, sm, ah};
+    inst = __builtin_amdgcn_readlane(inst, lrow * LW);
+    rowoff = (unsigned)inst * LW + j;
+    rs = c.rs - (lane >> 4) + lrow;
+    sm = c.sm - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
+    ah = c.ah - lane + lrow * LW + j;
+    return c;
+  }
+  __device__ __forceinline__ void lone_leave(const LoneCtx& c) {
+    inst = c.inst;
+    rowoff = c.rowoff;
+    rs = c.rs;
+    sm = c.sm;
+    ah = c.ah;
+  }
+  // the row of the wave (0..3) a wave-uniform ballot of a per-row flag names, and how many rows it names
+  static __device__ __forceinline__ int rows_in(unsigned long long b) {
+    return (int)((b & 1ull) + ((b >> 16) & 1ull) + ((b >> 32) & 1ull) + ((b >> 48) & 1ull));
+  }
+  static __device__ __forceinline__ int first_row(unsigned long long b) {
+    return ((b >> 16) & 1ull) ? 1 : (((b >> 32) & 1ull) ? 2 : (((b >> 48) & 1ull) ? 3 : 0));
+  }
+  static __device__ __forceinline__ double row_value(double v, int lrow) {  // v of row lrow (any lane of it), wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lrow * LW);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lrow * LW);
     return __hiloint2double(hi, lo);
   }
 
@@ -1899,28 +1956,14 @@ struct Solver {
             const int nbwr = (int)((bm & 1ull) + ((bm >> 16) & 1ull) + ((bm >> 32) & 1ull) + ((bm >> 48) & 1ull));
             if (!CONES && P.lone && !with_rho && nbwr == 1) {
               // exactly one row needs the pass: all four DPP rows work on that row's instance (backward_lone)
-              const int lrow = ((bm >> 16) & 1ull) ? 1 : (((bm >> 32) & 1ull) ? 2 : (((bm >> 48) & 1ull) ? 3 : 0));
-              const int inst_s = inst;
-              const unsigned rowoff_s = rowoff;
-              RowState* const rs_s = rs;
-              double* const sm_s = sm;
-              AHash* const ah_s = ah;
-              inst = __builtin_amdgcn_readlane(inst, lrow * LW);
-              rowoff = (unsigned)inst * LW + j;
-              rs = rs_s - (lane >> 4) + lrow;
-              sm = sm_s - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
-              ah = ah_s - lane + lrow * LW + j;
+              const LoneCtx ctx = lone_enter(first_row(bm));
               double a1, a2;
               bool dt;
               if constexpr (!CONES) {
                 if (o.strict) backward_lone<true>(a1, a2, fail, dt);
                 else backward_lone<false>(a1, a2, fail, dt);
               }
-              inst = inst_s;
-              rowoff = rowoff_s;
-              rs = rs_s;
-              sm = sm_s;
-              ah = ah_s;
+              lone_leave(ctx);
               if (bwrow) {
                 dV1 = a1;
                 dV2 = a2;
@@ -2039,7 +2082,23 @@ struct Solver {
             if (!wave_any(searching)) break;
             ALTRO_STAMP(long long ts = stamp();)
             Trials T;
-            trial_costs(alpha, T);
+            unsigned long long sb = __ballot(searching);
+            if (CONES && P.lone && rows_in(sb) < IPW) {
+              // fewer than four rows are searching: their sweeps run one after the other, each over all four DPP rows
+              // (a quarter of the knots per row), which takes rows/4 of the time of one row-parallel sweep
+              while (sb != 0ull) {
+                const int lrow = first_row(sb);
+                const double a_l = row_value(alpha, lrow);
+                const LoneCtx ctx = lone_enter(lrow);
+                Trials Tl;
+                trial_costs<true>(a_l, Tl);
+                lone_leave(ctx);
+                if ((lane >> 4) == lrow) T = Tl;
+                sb &= ~(0xFFFFull << (16 * lrow));
+              }
+            } else {
+              trial_costs<false>(alpha, T);
+            }
             ALTRO_STAMP(t_ls += stamp() - ts; c_ls++;)
             const double a0 = alpha;
             sfor<0, NA>([&](auto t) {
@@ -2053,7 +2112,19 @@ struct Solver {
           }
           if (wave_any(need_interp)) {
             ALTRO_STAMP(long long ts = stamp();)
-            interpolate(alpha, need_interp);
+            unsigned long long ib = __ballot(need_interp);
+            if (CONES && P.lone && rows_in(ib) < IPW) {
+              while (ib != 0ull) {
+                const int lrow = first_row(ib);
+                const double a_l = row_value(alpha, lrow);
+                const LoneCtx ctx = lone_enter(lrow);
+                interpolate<true>(a_l, true);
+                lone_leave(ctx);
+                ib &= ~(0xFFFFull << (16 * lrow));
+              }
+            } else {
+              interpolate<false>(alpha, need_interp);
+            }
             ALTRO_STAMP(t_ls += stamp() - ts;)
           }
           // ---- bookkeeping of this iteration (record_iteration!, evaluate_convergence)
