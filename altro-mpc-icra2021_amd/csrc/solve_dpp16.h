@@ -2259,7 +2259,9 @@ struct Solver {
 // each in the reference's order (random_linear_problem.jl:125-139,161): plant step + noise -> x0;
 // reference window <- step+1; shift_fill primal and dual; solve.
 template <int NX, int NU, bool CONES>
-__global__ void __launch_bounds__(64, CONES ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
+// (NU > 4: the gain rows of the first-order sweep and of the closed-loop rollout outgrow 256 registers -- (6,6): 188 spilled
+//  VGPRs at two waves per SIMD, none at one)
+__global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
   __shared__ altro::AHash hashes[128];

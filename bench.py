@@ -213,6 +213,23 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
     return out
 
 
+def _capped(mp, altro, cap, K, W, B):
+    """The same closed loops once more with Altro's `iterations` option (the total iLQR iterations one solve may take,
+    default 1000) set to `cap`, as an MPC deployment with a tick deadline would: a solve that hits it reports
+    MAX_ITERATIONS and the loop goes on from the trajectory it holds.  Without it a launch lasts as long as its slowest
+    instance (single solves of several hundred iterations at the penalty cap: tools/gpu_rocket_tail.py)."""
+    altro.set_options(mp.solver, iterations=cap)
+    altro.timing_reset(mp.solver)
+    t0 = time.perf_counter()
+    mp.run_async(K, first=W + K)
+    mp.synchronize()
+    dt = time.perf_counter() - t0
+    nsol, nit, nok = altro.solve_counters(mp.solver)
+    return {"iterations_option": cap, "value": B * K / dt, "unit": "solves/s", "steps": K, "ms_per_step": 1e3 * dt / K,
+            "solve_succeeded_frac": float(nok.sum() / max(1, nsol.sum())), "iterations_mean": float(nit.sum() / max(1, nsol.sum())),
+            "note": "the K steps after the line's own, Altro option iterations = %d; not the reference's configuration (its scripts leave the default 1000)" % cap}
+
+
 def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
     """BASELINE configs[2..4] on ONE GPU at their per-GPU sizes.  `--config <name>` prints them as lines of their own; the
     default run carries short versions (<= 10 steps) inside the headline line's `secondary` list."""
@@ -228,7 +245,7 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
 
     if which in ("rocket", "all"):   # configs[2]: rocket landing, second-order cones, N_mpc = 100, batch 4096
         B, Nm, Nt, dt = 4096, 100, 301, 0.05
-        K2 = min(K, Nt - Nm - 1 - W)
+        K2 = min(K, (Nt - Nm - 1 - W) // 2)
         rp = P.gen_rocket_problem(N=Nt, tf=(Nt - 1) * dt, Qfk=1e4, Rk=1.0, theta_thrust_max=5.0, theta_glideslope=45.0)
         rng = np.random.default_rng(1)
         x0 = np.tile(rp.x0, (B, 1)) + rng.standard_normal((B, 6)) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
@@ -239,11 +256,13 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
         tp = P.gen_rocket_problem(N=Nm, tf=dt * (Nm - 1), include_goal=False, theta_thrust_max=5.0, theta_glideslope=45.0)
         tp.Q, tp.R, tp.Qf = np.full(6, 10.0), np.full(3, 0.1), np.full(6, 10.0)
         prob = mpcm.constrained_problem(tp, Xt[:, 0].copy(), Xt[:, :Nm].copy(), Ut[:, :Nm - 1].copy(), U0=Ut[:, :Nm - 1].copy())
-        mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, rng.standard_normal((W + K2, B, 6)),
+        mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, rng.standard_normal((W + 2 * K2, B, 6)),
                            (np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])))
         mp.initial_solve()
-        done(_secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
-                             "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro, traffic_key=("rocket", "solve_kernel")))
+        line = _secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
+                               "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro, traffic_key=("rocket", "solve_kernel"))
+        line["with_iteration_cap"] = _capped(mp, altro, 100, K2, W, B)
+        done(line)
         mp.solver.close()
     if which in ("state_dim", "all"):   # configs[3]: state-dimension sweep, m = 4, N = 50, 8192 instances per GPU
         for n in state_dims:
@@ -263,7 +282,7 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
         rng = np.random.default_rng(17)
         t0 = rng.uniform(0.0, 0.8, B)
         x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
-        T = W + K4 + N
+        T = W + 2 * K4 + N
         A, Bm, d = np.zeros((B, T, 12, 12)), np.zeros((B, T, 12, 12)), np.zeros((B, T, 12))
         cache = {}
         for b in range(B):
@@ -272,15 +291,17 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
                 if c not in cache:
                     cache[c] = P.quadruped_linearize(qp.x_des, np.zeros(12), qp.feet, np.array(c), qp.inertia, qp.mass, qp.dt)
                 A[b, t], Bm[b, t], d[b, t] = cache[c]
-        Nt = W + K4 + N + 1
+        Nt = W + 2 * K4 + N + 1
         prob = mpcm.quadruped_problem(qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
         mp = mpcm.TrackMPC(prob, api.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
-                           rng.standard_normal((W + K4, B, 12)), (np.full(12, 1e-3),))
+                           rng.standard_normal((W + 2 * K4, B, 12)), (np.full(12, 1e-3),))
         api.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
         api.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))
         mp.initial_solve()
-        done(_secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
-                             "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel")))
+        line = _secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
+                               "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel"))
+        line["with_iteration_cap"] = _capped(mp, altro, 50, K4, W, B)
+        done(line)
         mp.solver.close()
     return lines
 

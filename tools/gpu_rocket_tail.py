@@ -40,7 +40,7 @@ wc = altro.wave_cycles(mp.solver)
 if wc.size:
     wc = wc.astype(float)
     print("  wave cycles: mean %.1fM p50 %.1fM p99 %.1fM max %.1fM" % (wc[:, 0].mean() / 1e6, np.median(wc[:, 0]) / 1e6, np.percentile(wc[:, 0], 99) / 1e6, wc[:, 0].max() / 1e6))
-    names = ["total", "backward", "closed", "open", "todorov", "dual", "ls"]
+    names = ["total", "bw4", "closed", "open", "todorov", "dual", "ls", "nlone", "bwlone", "fosweep", "adjoint", "nbw4", "nfo", "naj", "nrc", "nls"]
     print("  mean wave  :", " ".join("%s %.1fM" % (n, wc[:, i].mean() / 1e6) for i, n in enumerate(names)))
     w = int(np.argmax(wc[:, 0]))
     print("  slowest wave:", " ".join("%s %.1fM" % (n, wc[w, i] / 1e6) for i, n in enumerate(names)), "| row iterations", ni.reshape(-1, 4)[w].tolist(), "backward passes", nb.reshape(-1, 4)[w].tolist(), "trials", ntr.reshape(-1, 4)[w].tolist())
