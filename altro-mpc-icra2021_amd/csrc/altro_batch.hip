@@ -63,6 +63,7 @@ struct altro_handle {
   bool debug_keep_gains = false;           // ALTRO_DEBUG_KEEP_GAINS=1 at create time: the setters do NOT drop the stored gains (exists
                                            // to show that the tests notice stale gains; never set in production)
   int group = 1;                           // ALTRO_NO_GROUP=1 at create time: identity
+  int dbg_wave = -1;                       // ALTRO_DEBUG_TRACE_WAVE (diagnostic builds only)
   int resync = 1;                          // ALTRO_NO_RESYNC=1 at create time: rows never wait for their wave-mates
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
@@ -327,26 +328,29 @@ __global__ void k_plane_copy(double* __restrict__ Zp, double* __restrict__ Zs, c
 // the REFERENCE tells which windows those are: score = number of the launch's steps whose window holds a reference
 // knot at (or within 2 % of) a bound.  It is a scheduling heuristic only: results do not depend on which rows share a
 // wave (tests: instance results do not depend on the batch; lone-row == four-row pass bit for bit).
+// one 16-lane row per instance (lane j = element j of z: coalesced 128-byte reads), 16 instances per block
 __global__ void k_group_score(const double* __restrict__ Zref, const double* __restrict__ zmin, const double* __restrict__ zmax,
                               int* __restrict__ score, int Bp, int first, int nsteps, int k0, int k1, int nz) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= Bp) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = t / LW, j = t % LW;
+  const bool live = b < Bp;
+  const int bb = live ? b : Bp - 1;
   const int W = k1 - k0 + 1;                 // knots of a window that carry the box rows
   const int a0 = first + 1 + k0;             // first absolute knot touched by the launch's windows
   const int na = nsteps + W - 1;             // absolute knots touched
+  if (na > 256 || W < 1) { if (live && j == 0) score[b] = 0; return; }
+  const double lo = zmin[j], hi = zmax[j];
+  const bool fl = (j < nz) && lo > -1e300, fh = (j < nz) && hi < 1e300;
+  const double m = 0.02 * ((fl && fh) ? 0.5 * (hi - lo) : fmax(1.0, fabs(fh ? hi : lo)));
   unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
-  if (na > 256 || W < 1) { score[b] = 0; return; }
+  const int sh = (threadIdx.x & 63) & ~15;   // this row's 16 bits of the wave's ballot
   for (int a = 0; a < na; ++a) {
-    const double* z = Zref + ((size_t)(a0 + a) * Bp + b) * LW;
-    bool act = false;
-    for (int e = 0; e < nz; ++e) {
-      const double lo = zmin[e], hi = zmax[e];
-      const bool fl = lo > -1e300, fh = hi < 1e300;
-      const double m = 0.02 * ((fl && fh) ? 0.5 * (hi - lo) : fmax(1.0, fabs(fh ? hi : lo)));
-      act |= (fh && z[e] >= hi - m) || (fl && z[e] <= lo + m);
-    }
-    if (act) bits[a >> 6] |= 1ull << (a & 63);
+    const double z = Zref[((size_t)(a0 + a) * Bp + bb) * LW + j];
+    const bool act = (fh && z >= hi - m) || (fl && z <= lo + m);
+    const bool any = ((__ballot(act) >> sh) & 0xFFFFull) != 0ull;
+    if (any) bits[a >> 6] |= 1ull << (a & 63);
   }
+  if (!live || j != 0) return;
   int cnt = 0, sc = 0;
   for (int a = 0; a < W; ++a) cnt += (int)((bits[a >> 6] >> (a & 63)) & 1ull);
   for (int st = 0; st < nsteps; ++st) {
@@ -358,24 +362,42 @@ __global__ void k_group_score(const double* __restrict__ Zref, const double* __r
   score[b] = sc;
 }
 
-// perm[rank of instance i among (score, i)] = i: a deterministic sort by counting (Bp^2 compares: microseconds)
-__global__ void k_group_rank(const int* __restrict__ score, int* __restrict__ perm, int Bp, int mode) {
-  __shared__ int tile[1024];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int si = i < Bp ? score[i] : 0;
-  int rank = 0;
-  for (int t0 = 0; t0 < Bp; t0 += 1024) {
-    for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (t0 + t < Bp) ? score[t0 + t] : 0x7fffffff;
-    __syncthreads();
-    const int tn = (Bp - t0 < 1024) ? Bp - t0 : 1024;
-    for (int t = 0; t < tn; ++t) {
-      const int sj = tile[t];
-      rank += (sj < si || (sj == si && t0 + t < i)) ? 1 : 0;
-    }
-    __syncthreads();
+// perm = the instances in ascending order of (score, index): a stable counting sort in ONE block of 256 threads (thread t
+// owns a contiguous chunk of instances; scores are at most GROUP_BINS - 1 = the steps of a grouped launch)
+constexpr int GROUP_BINS = 33;
+__global__ void __launch_bounds__(256) k_group_rank(const int* __restrict__ score, int* __restrict__ perm, int Bp, int mode) {
+  __shared__ int cnt[GROUP_BINS][257];
+  __shared__ int base[GROUP_BINS + 1];
+  const int t = threadIdx.x;
+  const int chunk = (Bp + 255) / 256;
+  const int i0 = t * chunk, i1 = (i0 + chunk < Bp) ? i0 + chunk : Bp;
+  for (int b = 0; b < GROUP_BINS; ++b) cnt[b][t] = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int sc = score[i] < GROUP_BINS - 1 ? score[i] : GROUP_BINS - 1;
+    cnt[sc][t] += 1;
   }
-  if (i < Bp) {
-    const int W = Bp / 4;
+  __syncthreads();
+  if (t < GROUP_BINS) {  // exclusive prefix over the threads, per bin
+    int acc = 0;
+    for (int q = 0; q < 256; ++q) {
+      const int c = cnt[t][q];
+      cnt[t][q] = acc;
+      acc += c;
+    }
+    cnt[t][256] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int b = 0; b < GROUP_BINS; ++b) { base[b] = acc; acc += cnt[b][256]; }
+  }
+  __syncthreads();
+  const int W = Bp / 4;
+  int off[GROUP_BINS];
+  for (int b = 0; b < GROUP_BINS; ++b) off[b] = base[b] + cnt[b][t];
+  for (int i = i0; i < i1; ++i) {
+    const int sc = score[i] < GROUP_BINS - 1 ? score[i] : GROUP_BINS - 1;
+    const int rank = off[sc]++;
     int slot = rank;                                  // mode 1: sorted, the instances with the fewest expected passes first
     if (mode == 2) {                                  // sorted waves, light and heavy ones alternating in the block order
       const int wr = rank / 4, q = rank % 4;
@@ -410,7 +432,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.reuse = h->reuse; p.resync = h->resync;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
   p.Dff = h->Dff; p.ahash = h->ahash; p.kmu = h->kmu; p.n_fo = h->n_fo;
   p.Qz = h->Qz;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta;
@@ -432,9 +454,9 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   //  instances and clustering the pass-heavy rows -- they are also the ones with the hard solves -- lengthens the tail:
   //  measured 20 steps +2 %, 100 steps -3 %, tools/gpu_ab.py)
   if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && nsteps <= 32 && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
-    hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
+    hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
                        first_step, nsteps, h->box_k0, h->box_k1, h->d.n + h->d.m);
-    hipLaunchKernelGGL(k_group_rank, grid_for((size_t)h->Bp), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp, h->group);
+    hipLaunchKernelGGL(k_group_rank, dim3(1), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp, h->group);
     p.perm = h->perm;
   }
   const dim3 grid(h->Bp / IPW), block(64);
@@ -609,6 +631,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->device = device;
     { const char* nl = getenv("ALTRO_NO_LONE"); h->lone = (nl && nl[0] == '1') ? 0 : 1; }
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
+    { const char* dw = getenv("ALTRO_DEBUG_TRACE_WAVE"); h->dbg_wave = dw ? atoi(dw) : -1; }
     { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
     { const char* ng = getenv("ALTRO_NO_GROUP"); h->group = (ng && ng[0] == '1') ? 0 : 1; }
     { const char* gm = getenv("ALTRO_GROUP_MODE"); if (gm && gm[0] >= '0' && gm[0] <= '3') h->group = gm[0] - '0'; }
@@ -701,7 +724,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemsetAsync(h->atrace, 0, Bp * ALTRO_TRACE_LEN * sizeof(double), h->stream));
     CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
-    CCHK(hipMalloc(&h->wave_cycles, Bp * 4 * sizeof(long long)));
+    CCHK(hipMalloc(&h->wave_cycles, (Bp * 4 + 4096) * sizeof(long long)));
     CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
@@ -714,7 +737,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMemsetAsync(h->n_solves, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_iters, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_ok, 0, Bp * sizeof(long long), h->stream));
-    CCHK(hipMemsetAsync(h->wave_cycles, 0, Bp * 4 * sizeof(long long), h->stream));
+    CCHK(hipMemsetAsync(h->wave_cycles, 0, (Bp * 4 + 4096) * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_backward, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->n_rollout, 0, Bp * sizeof(long long), h->stream));
     CCHK(hipMemsetAsync(h->Z, 0, (2 * N + 1) * row * sizeof(double), h->stream));
@@ -1528,7 +1551,9 @@ int32_t altro_batch_get_wave_cycles(altro_handle* h, int64_t* cycles, int32_t ca
     if (!h || !count) return ALTRO_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int32_t n = h->Bp / IPW * 16;
+    // (diagnostic builds append a 4096-word per-turn trace of one wave, ALTRO_DEBUG_TRACE_WAVE: returned to callers that
+    //  offer the room)
+    const int32_t n = h->Bp / IPW * 16 + ((capacity >= h->Bp / IPW * 16 + 4096) ? 4096 : 0);
     *count = n;
     if (cycles) HIPCHK(h, hipMemcpy(cycles, h->wave_cycles, (size_t)(n < capacity ? n : capacity) * sizeof(long long), hipMemcpyDeviceToHost));
     return ALTRO_OK;

@@ -124,6 +124,7 @@ struct SolveParams {
   const int* bslot;      // [16] slot of lane j's element among the bounded ones, -1 if unbounded
   int nbp;               // slots per side (>= 1)
   double* mu;            // [Bp] box penalty (uniform over rows/knots)
+  int dbg_wave;          // -DALTRO_PHASE_STAMPS builds: the wave whose turns are traced behind the wave_cycles records
   int resync;            // 1: rows wait a turn to stay in step with their wave-mates (run(), phase A)
   int reuse;             // 1: gain reuse (fosweep) allowed; ALTRO_NO_REUSE=1 at create time switches it off
   int lone;              // 1: a backward pass that only one row of a wave needs runs spread over the four DPP rows (backward_lone)
@@ -906,8 +907,15 @@ struct Solver {
     const bool so2 = P.o.soc_second_order != 0;
     constexpr int UN = CONES ? 2 : ALTRO_UN;  // cone tables cost registers
     const int nch = LONE ? (N + 4 * UN - 1) / (4 * UN) : (N + UN - 1) / UN;
+    // The cost of a trial is summed in FOUR classes of chunks (chunk index mod 4), each in ascending order, and the
+    // classes are added as (J0 + J1) + (J2 + J3): the lone sweep, where DPP row r holds exactly class r, and the
+    // row-parallel sweep then produce the same bits (the scheduling switches must not change results).
+    double Jcls[NA][4];
+    sfor<0, NA>([&](auto t) { sfor<0, 4>([&](auto q) { Jcls[decltype(t)::value][decltype(q)::value] = 0.0; }); });
     for (int c = 0; c < nch; ++c) {
       const int k0 = LONE ? (4 * c + rr) * UN : c * UN;
+      const int cls = LONE ? 0 : (c & 3);
+      sfor<0, NA>([&](auto t) { Jacc[decltype(t)::value] = 0.0; });
       double z[UN], zz1[UN], zr[UN], lhi[UN], llo[UN], lcq[UN];
       ConK ckq[UN];
       sfor<0, UN>([&](auto q) {
@@ -955,10 +963,18 @@ struct Solver {
           chg[Tt] = chg[Tt] | (on & (zb != z[Q]));
         });
       });
+      sfor<0, NA>([&](auto t) {
+        constexpr int Tt = decltype(t)::value;
+        sfor<0, 4>([&](auto q) {
+          constexpr int Q = decltype(q)::value;
+          Jcls[Tt][Q] += (cls == Q) ? Jacc[Tt] : 0.0;
+        });
+      });
     }
     sfor<0, NA>([&](auto t) {
       constexpr int Tt = decltype(t)::value;
-      T.J[Tt] = LONE ? rows_sum4(row_sum(Jacc[Tt])) : row_sum(Jacc[Tt]);
+      T.J[Tt] = LONE ? rows_sum4(row_sum(Jcls[Tt][0]))
+                     : (row_sum(Jcls[Tt][0]) + row_sum(Jcls[Tt][1])) + (row_sum(Jcls[Tt][2]) + row_sum(Jcls[Tt][3]));
       T.cmax[Tt] = LONE ? rows_max4(row_max(viol[Tt])) : row_max(viol[Tt]);
       T.limit[Tt] = LONE ? wave_any(lim[Tt]) : row_any(lim[Tt], lane);
       T.unchanged[Tt] = LONE ? !wave_any(chg[Tt]) : !row_any(chg[Tt], lane);
@@ -1895,6 +1911,16 @@ struct Solver {
         // ... and for the rest of the launch once the wave trails the two-turns-per-step pace by ALTRO_PRIO_LAG turns:
         // its partner on the SIMD has that much slack, the launch does not
         turns++;
+#ifdef ALTRO_PHASE_STAMPS
+        if ((int)blockIdx.x == P.dbg_wave && turns < 4096 && (lane & 15) == 0) {
+          // per turn and row: phase | it << 4 | iters << 12 | step << 20 | outer << 28
+          long long* tr = P.wave_cycles + (size_t)gridDim.x * 16 + turns;
+          const long long code = (long long)rs->phase | ((long long)(rs->it & 255) << 4) | ((long long)(rs->iters & 255) << 12) | ((long long)(rs->step & 255) << 20) | ((long long)(rs->outer & 15) << 28);
+          // four rows packed 16 bits apart would overflow: one word per row, interleaved
+          P.wave_cycles[(size_t)gridDim.x * 16 + (size_t)(turns & 1023) * 4 + (lane >> 4)] = code;
+          (void)tr;
+        }
+#endif
         const RowState* r0 = rs - (lane >> 4);
         int ms = r0[0].step;
         sfor<1, IPW>([&](auto q) { ms = imin(ms, r0[decltype(q)::value].step); });
@@ -2083,7 +2109,7 @@ struct Solver {
             ALTRO_STAMP(long long ts = stamp();)
             Trials T;
             unsigned long long sb = __ballot(searching);
-            if (CONES && P.lone && rows_in(sb) < IPW) {
+            if (P.lone && rows_in(sb) < IPW) {
               // fewer than four rows are searching: their sweeps run one after the other, each over all four DPP rows
               // (a quarter of the knots per row), which takes rows/4 of the time of one row-parallel sweep
               while (sb != 0ull) {
@@ -2113,7 +2139,7 @@ struct Solver {
           if (wave_any(need_interp)) {
             ALTRO_STAMP(long long ts = stamp();)
             unsigned long long ib = __ballot(need_interp);
-            if (CONES && P.lone && rows_in(ib) < IPW) {
+            if (P.lone && rows_in(ib) < IPW) {
               while (ib != 0ull) {
                 const int lrow = first_row(ib);
                 const double a_l = row_value(alpha, lrow);

@@ -30,7 +30,7 @@ def counters(d):
     return {k: sorted(v)[-1][1] for k, v in per.items()}     # the timed (fused) launch is the last dispatch of the kernel
 
 
-entries, summary = [], {"source": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --stats / --pmc passes of `python3 bench.py <args> --no-cpu-baseline`" % tag}
+entries, summary = [], {"source": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --stats / --pmc passes of `python3 bench.py <args> --no-cpu-baseline --no-secondary --repeats 1` (the timed K-step region of the headline line: the last dispatch of the kernel)" % tag}
 for name, cfg in CONFIGS.items():
     ks = find(name + "/kt", "*kernel_stats.csv")
     if ks:
