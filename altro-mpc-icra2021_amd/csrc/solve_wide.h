@@ -2709,7 +2709,10 @@ typedef void (*wide_kernel_t)(Params, int, int, int);
 inline int wide_class(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : 0; }
 inline wide_kernel_t wide_kernel_for(int n, int m) {
 #ifdef ALTRO_DEV_HEADLINE_ONLY  // development builds (tools/build_stamps.sh -DALTRO_DEV_HEADLINE_ONLY): one small instantiation
-  return wide_kernel<4, true>;
+#ifndef ALTRO_DEV_WIDE_KERNEL
+#define ALTRO_DEV_WIDE_KERNEL wide_kernel<4, true>
+#endif
+  return ALTRO_DEV_WIDE_KERNEL;  // e.g. '-DALTRO_DEV_WIDE_KERNEL=wide_kernel<4,false>' (30 s instead of 4 min)
 #else
   const bool sm = n <= 16 && m <= 16;
   switch (wide_class(m)) {

@@ -151,9 +151,10 @@ def flops_first_order(n, m, N):
     return (N - 1) * (2 * n * (n + m) + 2 * n * m + 2 * m * m + 6 * m)
 
 
-def secondary_traffic(key):
+def secondary_traffic(key, steps=None):
     """HBM bytes of the timed launch of a secondary line from the committed rocprofv3 PMC passes
-    (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring)."""
+    (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring);
+    only a profile of a launch with the same number of fused steps counts."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_secondary_kernels.json"))):
@@ -161,7 +162,10 @@ def secondary_traffic(key):
             t = json.load(open(path))
         except (OSError, ValueError):
             continue
-        for rec in (t.get(key[0]) or {}).get("launches", []):
+        ent = t.get(key[0]) or {}
+        if steps is not None and not any(bl.get("steps") == steps for bl in ent.get("bench_lines", [])):
+            continue
+        for rec in ent.get("launches", []):
             if key[1] in rec.get("kernel", "") and "hbm_bytes" in rec:
                 best = rec["hbm_bytes"]
     return best
@@ -196,7 +200,7 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic", "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B},
            "roofline": {"bound": bound, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": secondary_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "avg_launch_ms": avg_ms,
+                        "traffic": secondary_traffic(traffic_key, K) if traffic_key else None, "kernel": kernel, "avg_launch_ms": avg_ms,
                         "launches": int(len(ms)),
                         "executed": {"achieved": executed, "frac": executed / FP64_PEAK_TFLOPS},
                         "note": "achieved: SURVEY 8(d) flops_solve (measured iterations and trials x the base Riccati / rollout formulas; "

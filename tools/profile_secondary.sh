@@ -8,7 +8,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_sec_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-for CFG in "quadruped:--config quadruped --steps 20 --warmup 5" "state_dim:--config state_dim --steps 10 --warmup 5" "rocket:--config rocket --steps 10 --warmup 5"; do
+for CFG in "quadruped:--config quadruped --steps 10 --warmup 3" "state_dim:--config state_dim --steps 10 --warmup 3" "rocket:--config rocket --steps 10 --warmup 3"; do  # the steps of the default run's secondary lines
   NAME=${CFG%%:*}
   ARGS=${CFG#*:}
   rocprofv3 --kernel-trace --stats -d $OUT/$NAME/kt -o kt --output-format csv -- python3 bench.py $ARGS > $OUT/$NAME.kt.log 2>&1
