@@ -1649,3 +1649,28 @@ def test_projected_newton_polish_matches_oracle(oracle):
         mp.step(0)
     with pytest.raises(altro.AltroError):
         altro.ALTROSolver(altro.mpc.gen_tracking_problem(altro.problems.gen_random_linear_batch(2, n=20, m=4, N=11, steps=1)), altro.SolverOptions(**opts))
+
+
+def test_initial_state_uploaded_before_per_knot_dynamics_survives_the_move_to_the_wide_kernel():
+    """altro_batch_set_initial_state before altro_batch_set_dynamics(per_knot = 1) on a 16-lane size: the handle moves to
+    the one-wave-per-instance backend and carries x0 over (it used to be dropped silently)."""
+    import ctypes as C
+    L = altro._lib.lib()
+    B, n, m, N = 3, 12, 4, 9
+    dims = altro._lib.Dims(B, n, m, N)
+    opts = altro.SolverOptions(**REF_OPTS)
+    h = C.c_void_p()
+    assert L.altro_batch_create(C.byref(dims), C.byref(opts), 0, C.byref(h)) == 0
+    try:
+        rng = np.random.default_rng(5)
+        x0 = np.ascontiguousarray(rng.standard_normal((B, n)))
+        dp = C.POINTER(C.c_double)
+        assert L.altro_batch_set_initial_state(h, x0.ctypes.data_as(dp)) == 0
+        A = np.ascontiguousarray(np.tile(np.eye(n) * 0.9, (N - 1, 1, 1)))
+        Bm = np.ascontiguousarray(rng.standard_normal((N - 1, m, n)))       # column-major n x m blocks
+        assert L.altro_batch_set_dynamics(h, A.ctypes.data_as(dp), Bm.ctypes.data_as(dp), None, 1, 0) == 0
+        out = np.zeros((B, n))
+        assert L.altro_batch_get_initial_state(h, out.ctypes.data_as(dp)) == 0
+        assert np.array_equal(out, x0)
+    finally:
+        L.altro_batch_destroy(h)
