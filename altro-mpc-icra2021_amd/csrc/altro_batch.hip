@@ -76,6 +76,8 @@ struct altro_handle {
   // generic affine constraints packed into 4 quads of 4 constraint rows (see solve_dpp16.h)
   double *Acon = nullptr, *bcon = nullptr, *Lc = nullptr;
   int* cmeta = nullptr;
+  int* ckn = nullptr;   // [16] canonical knot of each constraint lane (time-invariant tables, see pack_constraints)
+  int con_inv = 0;
   std::vector<double> Acon_h, bcon_h;  // per-knot tables [ninst][N][16][16], [ninst][N][16]; ninst = 1 (shared) or Bp
   bool con_per_instance = false;
   size_t acon_elems = 0;               // elements the device table Acon currently holds
@@ -435,7 +437,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
   p.Dff = h->Dff; p.ahash = h->ahash; p.kmu = h->kmu; p.n_fo = h->n_fo;
   p.Qz = h->Qz;
-  p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta;
+  p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.ckn = h->ckn; p.con_inv = h->con_inv;
   p.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u; p.Lc = h->Lc; p.ncrows = h->ncrows; p.KD = h->KD;
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace; p.atrace = h->atrace;
@@ -673,6 +675,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->Acon, N * LW * LW * sizeof(double)));
     CCHK(hipMalloc(&h->bcon, N * LW * sizeof(double)));
     CCHK(hipMalloc(&h->cmeta, N * LW * 4 * sizeof(int)));
+    CCHK(hipMalloc(&h->ckn, LW * sizeof(int)));
+    CCHK(hipMemsetAsync(h->ckn, 0, LW * sizeof(int), h->stream));
     CCHK(hipMalloc(&h->lanebuf, LW * sizeof(int)));
     CCHK(hipMalloc(&h->noise_w, LW * sizeof(double)));
     CCHK(hipMalloc(&h->noise_grp, LW * sizeof(int)));
@@ -776,7 +780,7 @@ static void free_dpp_backend(altro_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   void** ptrs[] = {(void**)&h->Gcol, (void**)&h->Grow, (void**)&h->fvec, (void**)&h->wd, (void**)&h->wf, (void**)&h->zmin, (void**)&h->zmax,
                    (void**)&h->x0, (void**)&h->Zref, (void**)&h->Z, (void**)&h->Lb, (void**)&h->bslot, (void**)&h->Acon, (void**)&h->bcon,
-                   (void**)&h->cmeta, (void**)&h->Lc, (void**)&h->lanebuf, (void**)&h->noise_w, (void**)&h->noise_grp, (void**)&h->mu,
+                   (void**)&h->cmeta, (void**)&h->ckn, (void**)&h->Lc, (void**)&h->lanebuf, (void**)&h->noise_w, (void**)&h->noise_grp, (void**)&h->mu,
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
@@ -989,6 +993,29 @@ static int pack_constraints(altro_handle* h) {
   HIPCHK(h, hipMemcpyAsync(h->Acon, h->Acon_h.data(), h->Acon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->bcon, h->bcon_h.data(), h->bcon_h.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->cmeta, h->cmeta_h.data(), h->cmeta_h.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  // Time-invariant tables (rocket landing: every constraint has ONE block of data and its own lanes): the row a lane
+  // holds is the same at every knot of its range, so the streaming sweeps load it once per sweep from one canonical
+  // knot instead of once per knot (solve_dpp16.h trial_costs).  Decided on the packed tables themselves.
+  {
+    bool inv = !h->con_per_instance;
+    int ckn[LW];
+    for (int lane = 0; lane < LW; ++lane) {
+      int first = -1;
+      for (int k = 0; k < N && inv; ++k) {
+        const size_t e = (size_t)k * LW + lane;
+        if (h->cmeta_h[4 * e] == 0) continue;
+        if (first < 0) { first = k; continue; }
+        const size_t f = (size_t)first * LW + lane;
+        for (int q = 0; q < 4; ++q) inv = inv && h->cmeta_h[4 * e + q] == h->cmeta_h[4 * f + q];
+        inv = inv && h->bcon_h[e] == h->bcon_h[f];
+        for (int jj = 0; jj < LW; ++jj) inv = inv && h->Acon_h[e * LW + jj] == h->Acon_h[f * LW + jj];
+      }
+      ckn[lane] = first < 0 ? 0 : first;
+    }
+    // a lane without rows must be empty at its canonical knot 0 too: true by construction (it is empty everywhere)
+    h->con_inv = inv ? 1 : 0;
+    HIPCHK(h, hipMemcpyAsync(h->ckn, ckn, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->con_dirty = false;
   return ALTRO_OK;

@@ -139,6 +139,9 @@ struct SolveParams {
   const int* cmeta;      // [N][16][4] per lane: type (0 none, 1 EQ, 2 INEQ, 3 SOC), k0, k1 of the row's
                          // constraint, p (dimension of the cone this lane's quad holds at this knot;
                          // linear rows may use the quad's spare lanes)
+  const int* ckn;        // [16] canonical knot of each constraint lane
+  int con_inv;           // 1: the row a lane holds is the same at every knot of its range (time-invariant tables): the
+                         // streaming sweeps load it once, from knot ckn[lane]
   double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
   int ncrows;            // 0: no generic constraints
   double* Qz;            // [N+1][Bp][16] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced
@@ -912,6 +915,9 @@ struct Solver {
     // row-parallel sweep then produce the same bits (the scheduling switches must not change results).
     double Jcls[NA][4];
     sfor<0, NA>([&](auto t) { sfor<0, 4>([&](auto q) { Jcls[decltype(t)::value][decltype(q)::value] = 0.0; }); });
+    ConK ck0;  // time-invariant constraint tables: this lane's row, loaded once for the whole sweep
+    const bool inv = CONES && (P.con_inv != 0);
+    if constexpr (CONES) con_load(inv ? P.ckn[j] : 0, ck0);
     for (int c = 0; c < nch; ++c) {
       const int k0 = LONE ? (4 * c + rr) * UN : c * UN;
       const int cls = LONE ? 0 : (c & 3);
@@ -929,7 +935,8 @@ struct Solver {
         lcq[Q] = 0.0;
         if constexpr (CONES) {
           lcq[Q] = ldg(P.Lc, at(k));
-          con_load(k, ckq[Q]);
+          if (inv) ckq[Q] = ck0;
+          else con_load(k, ckq[Q]);
         }
       });
       sfor<0, UN>([&](auto q) {
