@@ -30,6 +30,7 @@ nfo = altro.reuse_counter(mp.solver)
 print("per solve: iterations %.3f, backward passes %.3f, gains from memory %.3f, costate-confirmed %.3f, rollouts %.3f, trials %.3f; lone passes per wave %.1f" % (
     ni.sum() / ns.sum(), nb.sum() / ns.sum(), nfo.sum() / ns.sum(), ngc.sum() / ns.sum(), nr.sum() / ns.sum(), ntr.sum() / ns.sum(), wcs[:, 7].mean()))
 # the slowest waves: which phase carries their extra time, and how many turns of the wave loop they took
+print("(row iteration lists below name the instances 4w..4w+3: with grouping on, wave w holds OTHER instances -- run with ALTRO_NO_GROUP=1 for labels that match)")
 order = np.argsort(-wcs[:, 0])[:5]
 nit4 = ni.reshape(-1, 4)
 for w in order:
