@@ -65,7 +65,7 @@ class AltroError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Generate the DPP block include and compile the HIP library for gfx950, in tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "gen_dpp_blocks.py")]
+    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "pn_polish.h", "gen_dpp_blocks.py")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "altro_batch.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
