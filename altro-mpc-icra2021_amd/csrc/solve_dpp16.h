@@ -2309,6 +2309,13 @@ __global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SI
     ALTRO_STAMP(wc[1] = s.t_bw; wc[2] = s.t_rc; wc[3] = s.t_ro; wc[4] = s.t_td; wc[5] = s.t_du; wc[6] = s.t_ls; wc[8] = s.t_bl; wc[9] = s.t_fo; wc[10] = s.t_aj;
                 wc[11] = s.c_bw; wc[12] = s.c_fo; wc[13] = s.c_aj; wc[14] = s.c_rc; wc[15] = s.c_ls;)
     wc[7] = s.n_lone;
+#ifdef ALTRO_PHASE_STAMPS
+    {  // which SIMD the wave ran on (HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0): who shares a SIMD with whom
+      const unsigned a = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+      const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 0xf;
+      wc[4] = (long long)((x << 12) | (((a >> 13) & 7) << 9) | (((a >> 12) & 1) << 8) | (((a >> 8) & 15) << 2) | ((a >> 4) & 3));
+    }
+#endif
 #ifdef ALTRO_DIAG_REUSE
     wc[3] = s.d_same0; wc[4] = s.d_all0; wc[5] = s.d_same1; wc[6] = s.d_all1;
 #endif
