@@ -85,6 +85,7 @@ struct Params {
   // dyn_blocks = N - 1, stride 0; altro_mpc_set_dynamics_track a long table with stride 1 (blocks indexed by
   // absolute knot, like the reference track) or N - 1 (one full table per MPC step).
   int dyn_blocks, dyn_step_stride;
+  int compact;  // LDS carve-up with [Qux | Qu] and K inside W (wide_compact)
   altro_opts o;
 };
 
@@ -96,7 +97,15 @@ struct Lds {
   int G, S, W, Hux, Kl, Huu, Ac, DA, vec, cmd, total;
   int ldg, lds, ldh, ldu;
 };
-__host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
+// compact: [Qux | Qu] and K live in the two halves of W.  W = S [A B] is dead once the three products that read it have
+// issued, and the one-wave backward pass runs Qux = B' W_A as the LAST of them (one strip: every read of W precedes the
+// stores of the strip, and LDS instructions of a wave execute in order).  At n = 17..32, m <= 16 the carve-up falls
+// from 51.6 KB to 39.0 KB: four one-wave blocks per CU instead of three.
+__host__ __device__ inline bool wide_compact(int n, int m, int ltv, int np_max) {
+  const int np = (n + 15) & ~15, mp = (m + 15) & ~15;
+  return !(n <= 16 && m <= 16) && !ltv && mp == 16 && np >= 32 && np <= np_max && np <= 48;  // (n = 64 stays a cooperative block: its helper waves read W concurrently)
+}
+__host__ __device__ inline Lds lds_layout(int n, int m, int Pn, int compact = 0) {
   Lds L;
   const int np = pad16(n), mp = pad16(m), nzp = np + mp, Pp = pad4(Pn);
   L.ldg = nzp + 1;
@@ -107,8 +116,13 @@ __host__ __device__ inline Lds lds_layout(int n, int m, int Pn) {
   L.G = o; o += np * L.ldg;
   L.S = o; o += np * L.lds;
   L.W = o; o += np * L.ldg;
-  L.Hux = o; o += mp * L.ldh;
-  L.Kl = o; o += mp * L.ldh;
+  if (compact) {  // 2 mp ldh <= np ldg for mp = 16, np >= 32
+    L.Hux = L.W;
+    L.Kl = L.W + mp * L.ldh;
+  } else {
+    L.Hux = o; o += mp * L.ldh;
+    L.Kl = o; o += mp * L.ldh;
+  }
   L.Huu = o; o += mp * L.ldu;
   L.Ac = o; o += Pp * L.ldg;
   L.DA = o; o += Pp * L.ldg;
@@ -350,7 +364,7 @@ struct Solver {
 
   __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
-        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn)) {
+        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
     lds_base = lds;
     G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
     Ac = lds + ly.Ac; DA = lds + ly.DA;
@@ -2127,9 +2141,9 @@ struct Solver {
         } else {
           gemm_tn<false>(W, ldg, S, lds, G, ldg, np, nzp, np);  // W = S [A B]
           wsync();
-          gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A
           gemm_tn<false>(Huu, ldu, G + np, ldg, W + np, ldg, mp, mp, np);  // Quu = B' S B
           gemm_tn<false>(S, lds, G, ldg, W, ldg, np, np, np);              // Qxx = A' S A  (S is free: W is complete)
+          gemm_tn<false>(Hux, ldh, G + np, ldg, W, ldg, mp, np, np);       // Qux = B' S A: last, Hux may lie inside W (lds_layout)
           wsync();
         }
         if (ahead) dyn_park_G(dq);  // nothing reads G any more at this knot
@@ -2682,7 +2696,7 @@ template <int MC, bool SM>
 __global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
   if (!SM && threadIdx.x >= 64) {  // helper waves: no solver state, only products on command
-    coop_helper(lds, lds_layout(P.n, P.m, P.Pn).cmd);
+    coop_helper(lds, lds_layout(P.n, P.m, P.Pn, P.compact).cmd);
     return;
   }
   Solver<MC, SM> s(P, lds);

@@ -57,6 +57,7 @@ struct WideBackend {
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
   unsigned* bwst = nullptr;   // [B][136] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
+  int compact_np_max = 48;  // wide_compact: the LDS carve-up with Qux and K inside W, for padded state dimensions up to this
   bool debug_keep_gains = false;  // ALTRO_DEBUG_KEEP_GAINS=1 at create time: stale gains are kept (exists to show that the tests notice them)
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
@@ -111,6 +112,7 @@ struct WideBackend {
     o = *opts;
     device = dev;
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); debug_keep_gains = kg && kg[0] == '1'; }
+    if (const char* e = getenv("ALTRO_WIDE_COMPACT")) compact_np_max = atoi(e);  // diagnostic switch: 0 = never, 32 / 48 / 64 = up to that padded n
     WCHK(hipSetDevice(device));
     const Lds L = lds_layout(d.n, d.m, kMaxP);
     (void)L;
@@ -426,11 +428,16 @@ struct WideBackend {
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
+    p.compact = compact();
     p.o = o;
     return p;
   }
 
-  size_t lds_bytes() const { return (size_t)lds_layout(d.n, d.m, Pn).total * sizeof(double); }
+  int compact() const {  // only for one-wave blocks: the helper waves of a cooperative block read W while wave 0 writes Qux
+    if (!wide_compact(d.n, d.m, ltv, compact_np_max)) return 0;
+    return wide_block_threads(d.n, d.m, (size_t)lds_layout(d.n, d.m, Pn, 1).total * sizeof(double)) == 64 ? 1 : 0;
+  }
+  size_t lds_bytes() const { return (size_t)lds_layout(d.n, d.m, Pn, compact()).total * sizeof(double); }
 
   int prepare_launch() {
     if (!have_dyn) WFAIL(ALTRO_ERR_STATE, "altro_batch_set_dynamics has not been called");

@@ -48,6 +48,9 @@ struct orc_solver {
   int dJ_zero_counter;
   /* scratch */
   double *S, *s, *Qxx, *Quu, *Qux, *Qx, *Qu, *tmp_nn, *tmp_nm, *tmp_mm, *tmp_mn, *Quu_reg;
+  /* diagnostic (orc_debug_pass_trace): highest knot whose second-order cost expansion differs from the previous pass's */
+  int *dbg_buf, dbg_cap, dbg_n;
+  double *dbg_prev;
 };
 
 /* ---------------------------------------------------------------- options */
@@ -121,7 +124,7 @@ void orc_destroy(orc_solver* s) {
   free(s->Xref); free(s->Uref); free(s->x0); free(s->X); free(s->U); free(s->Xb); free(s->Ub);
   free(s->K); free(s->d); free(s->lxx); free(s->luu); free(s->lux); free(s->lx); free(s->lu);
   free(s->S); free(s->s); free(s->Qxx); free(s->Quu); free(s->Qux); free(s->Qx); free(s->Qu);
-  free(s->tmp_nn); free(s->tmp_nm); free(s->tmp_mm); free(s->tmp_mn); free(s->Quu_reg);
+  free(s->tmp_nn); free(s->tmp_nm); free(s->tmp_mm); free(s->tmp_mn); free(s->Quu_reg); free(s->dbg_prev);
   for (int i = 0; i < s->ncon; ++i) {
     con_t* c = &s->con[i];
     free(c->A); free(c->b); free(c->zmin); free(c->zmax); free(c->lam); free(c->mu); free(c->c);
@@ -165,6 +168,17 @@ void orc_set_controls(orc_solver* s, const double* U) {
 }
 
 void orc_set_opts(orc_solver* s, const orc_opts* o) { s->opts = *o; }
+
+/* diagnostic: every backward pass from now on appends to buf (up to cap entries) the highest knot whose second-order
+ * cost expansion (lxx, luu, lux: the active set and the penalties) differs from the previous pass's, -1 if none does.
+ * Returns the number of passes recorded so far and restarts the count. */
+int orc_debug_pass_trace(orc_solver* s, int* buf, int cap) {
+  int got = s->dbg_n;
+  s->dbg_buf = buf;
+  s->dbg_cap = cap;
+  s->dbg_n = 0;
+  return got;
+}
 
 /* add_constraint!(cons, con, inds) : random_linear_problem.jl:24 (C1-C8) */
 int orc_add_constraint(orc_solver* s, int kind, int sense, int k_first, int k_last, int p,
@@ -549,6 +563,23 @@ static int backward_pass(orc_solver* s, double dV[2]) {
   int n = s->n, m = s->m, N = s->N;
   double *S = s->S, *sv = s->s;
   int restart;
+  if (s->dbg_buf) {
+    size_t per = (size_t)n * n + (size_t)m * m + (size_t)m * n;
+    if (!s->dbg_prev) s->dbg_prev = dalloc((size_t)N * per);
+    int kc = -1;
+    for (int k = N - 1; k >= 0; --k) {
+      double* pv = s->dbg_prev + (size_t)k * per;
+      int same = !memcmp(pv, s->lxx + (size_t)k * n * n, sizeof(double) * n * n) &&
+                 !memcmp(pv + n * n, s->luu + (size_t)k * m * m, sizeof(double) * m * m) &&
+                 !memcmp(pv + n * n + m * m, s->lux + (size_t)k * m * n, sizeof(double) * m * n);
+      if (!same && kc < 0) kc = k;
+      memcpy(pv, s->lxx + (size_t)k * n * n, sizeof(double) * n * n);
+      memcpy(pv + n * n, s->luu + (size_t)k * m * m, sizeof(double) * m * m);
+      memcpy(pv + n * n + m * m, s->lux + (size_t)k * m * n, sizeof(double) * m * n);
+    }
+    if (s->dbg_n < s->dbg_cap) s->dbg_buf[s->dbg_n] = kc;
+    s->dbg_n++;
+  }
   do {
     restart = 0;
     memcpy(S, s->lxx + (size_t)(N - 1) * n * n, (size_t)n * n * sizeof(double));

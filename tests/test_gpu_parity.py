@@ -1395,6 +1395,35 @@ def test_scheduling_switches_do_not_change_results(monkeypatch):
     assert np.array_equal(ia, ib)               # iteration counts over all 14 steps, instance by instance
 
 
+@pytest.mark.parametrize("n", [32, 48])
+def test_wide_kernel_compact_lds_layout_does_not_change_results(monkeypatch, n):
+    """n = 17..48, m <= 16, time-invariant dynamics: [Qux | Qu] and K live inside the buffer of W = S [A B] (solve_wide.h
+    lds_layout, `compact`), which takes the carve-up from three one-wave blocks per CU to four (n <= 32) and from a
+    cooperative block to two one-wave blocks (n <= 48).  ALTRO_WIDE_COMPACT=0 is the separate-buffer layout: same bits."""
+    B, S = 24, 6
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=4, N=50, steps=S, seed=17)
+
+    def run():
+        mp = altro.mpc.BatchMPC(pb)
+        mp.initial_solve()
+        mp.run_async(S, first=0)
+        mp.synchronize()
+        return mp
+
+    a = run()
+    monkeypatch.setenv("ALTRO_WIDE_COMPACT", "0")
+    b = run()
+    monkeypatch.delenv("ALTRO_WIDE_COMPACT")
+    sa, sb = altro.stats(a.solver), altro.stats(b.solver)
+    assert (sa.status == 1).all()
+    assert np.array_equal(altro.states(a.solver), altro.states(b.solver)) and np.array_equal(altro.controls(a.solver), altro.controls(b.solver))
+    assert np.array_equal(altro.get_duals(a.solver), altro.get_duals(b.solver)) and np.array_equal(a.x0(), b.x0())
+    assert np.array_equal(sa.iterations, sb.iterations) and np.array_equal(sa.cost, sb.cost)
+    Ka, da = altro.gains(a.solver)
+    Kb, db = altro.gains(b.solver)
+    assert np.array_equal(Ka, Kb) and np.array_equal(da, db)
+
+
 @pytest.mark.parametrize("n", [48, 20])
 def test_wide_kernel_generic_rows_on_large_states(oracle, n):
     """Linear inequality rows, an equality at the terminal knot, a second-order cone and a control box on a random
