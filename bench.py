@@ -153,7 +153,8 @@ def flops_first_order(n, m, N):
 
 def secondary_traffic(key, steps=None):
     """HBM bytes of the timed launch of a secondary line from the committed rocprofv3 PMC passes
-    (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring);
+    (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring
+    [, {launch configuration}: the sweep points of one kernel differ in grid and block size]);
     only a profile of a launch with the same number of fused steps counts."""
     import glob
     best = None
@@ -166,7 +167,7 @@ def secondary_traffic(key, steps=None):
         if steps is not None and not any(bl.get("steps") == steps for bl in ent.get("bench_lines", [])):
             continue
         for rec in ent.get("launches", []):
-            if key[1] in rec.get("kernel", "") and "hbm_bytes" in rec:
+            if key[1] in rec.get("kernel", "") and "hbm_bytes" in rec and all(rec.get(k) == v for k, v in (key[2] if len(key) > 2 else {}).items()):
                 best = rec["hbm_bytes"]
     return best
 
@@ -276,8 +277,13 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
             mp = mpcm.BatchMPC(pb)
             mp.initial_solve()
             kern = "altro::solve_kernel<8,4>" if n == 8 else "altro_wide::wide_kernel<4>"
+            # launch configuration of the point in the committed profile: one wave per four instances (n = 8), per instance
+            # (n <= 48) or a cooperative block of four waves per instance (wide_block_threads)
+            wg = 256 if n > 48 else 64
+            tk = ("state_dim", "solve_kernel<8, 4" if n == 8 else "wide_kernel<4, true>" if n <= 16 else "wide_kernel<4, false>",
+                  {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg})
             done(_secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
-                                 kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro))
+                                 kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro, traffic_key=tk))
             mp.solver.close()
     if which in ("quadruped", "all"):   # configs[4]: quadruped contact-switching MPC, N = 40, 2048 instances per GPU, LTV loop on device
         B, N = 2048, 40

@@ -15,6 +15,14 @@ def find(d, pat):
     return f[0] if f else None
 
 
+def sig_of(r, trace):
+    """a launch configuration: lines that run the same kernel at several problem sizes (the state-dimension sweep)
+    differ in grid, block or LDS size"""
+    if trace:
+        return (r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]))
+    return (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["LDS_Block_Size"]))
+
+
 def counters(d):
     f = find(d, "*counter_collection.csv")
     per = {}
@@ -24,10 +32,10 @@ def counters(d):
     for r in csv.DictReader(open(f)):
         if not any(k in r["Kernel_Name"] for k in KERNELS):
             continue
-        key = (r["Kernel_Name"].split("(")[0], int(r["Dispatch_Id"]), r["Counter_Name"])
+        key = (sig_of(r, False), int(r["Dispatch_Id"]), r["Counter_Name"])
         acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
-    for (kern, disp, name), v in acc.items():
-        per.setdefault(kern, {}).setdefault(disp, {})[name] = v
+    for (sig, disp, name), v in acc.items():
+        per.setdefault(sig, {}).setdefault(disp, {})[name] = v
     return per
 
 
@@ -45,14 +53,15 @@ for name in ("quadruped", "state_dim", "rocket"):
     if kt:
         for r in csv.DictReader(open(kt)):
             if any(k in r["Kernel_Name"] for k in KERNELS):
-                durs.setdefault(r["Kernel_Name"].split("(")[0], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                durs.setdefault(sig_of(r, True), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     fe, wr, sq = counters(name + "/fetch"), counters(name + "/write"), counters(name + "/sq")
-    for kern, ds in durs.items():
-        # the timed (fused) launch of each line is the longest dispatch of its kernel
+    for sig, ds in durs.items():
+        # the timed (fused) launch of each line is the longest dispatch of its kernel and launch configuration
         i = max(range(len(ds)), key=lambda j: ds[j])
-        rec = {"kernel": kern, "dispatches": len(ds), "timed_launch_ms": ds[i] / 1e6}
+        rec = {"kernel": sig[0], "grid_size": sig[1], "workgroup_size": sig[2], "lds_block_size": sig[3], "dispatches": len(ds),
+               "timed_launch_ms": ds[i] / 1e6}
         for src in (fe, wr, sq):
-            disp = src.get(kern, {})
+            disp = src.get(sig, {})
             if disp:
                 best = max(disp.items(), key=lambda kv: sum(kv[1].values()))[1]   # the same (largest) launch in the PMC pass
                 rec.update(best)
