@@ -149,7 +149,8 @@ def test_mpc_loop_matches_oracle(oracle, n, m, N):
 
 
 @pytest.mark.parametrize("n,m,N", [(12, 6, 31), (2, 2, 21), (15, 2, 21), (35, 2, 21), (55, 2, 21), (30, 10, 21), (30, 25, 21),
-                                   (16, 4, 50), (32, 4, 50), (48, 4, 50), (64, 4, 50)])
+                                   (16, 4, 50), (32, 4, 50), (48, 4, 50), (64, 4, 50),
+                                   (17, 16, 12), (33, 5, 15), (48, 16, 12)])   # edges of the compact LDS carve-up (n = 17..48, m <= 16)
 def test_mpc_loop_wide_kernel_sizes_match_oracle(oracle, n, m, N):
     """Sizes outside the 16-lane kernel set run on the one-wave-per-instance MFMA kernel
     (solve_wide.h): the horizon sweep's (12, 6), points of the state- and control-dimension
