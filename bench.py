@@ -328,6 +328,10 @@ def main():
                     help="K-step regions timed back to back; `value` is the FIRST (W warm-up steps, then exactly K steps), the others are reported beside it")
     ap.add_argument("--config", default="headline", choices=["headline", "rocket", "state_dim", "quadruped", "all"],
                     help="headline (BASELINE configs[1], the driver's line) or a secondary config: extra JSON lines, 1 GPU only")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed GPU activity right before the timed region (elementwise torch kernels on a scratch buffer): the "
+                         "W warm-up steps are single launches with host work between them and leave the clocks wherever the idle "
+                         "GPU had them; 0 = none")
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="MPC steps per kernel launch in the timed region (0 = all K in one launch)")
     a = ap.parse_args()
@@ -385,6 +389,20 @@ def main():
         grp.barrier()
         return grp.max_over_ranks(time.perf_counter() - t0)
 
+    def preheat(ms_):
+        """keep the GPU busy for ms_ milliseconds with work that touches nothing of the solver"""
+        if ms_ <= 0:
+            return
+        dev = torch.device("cuda", local_rank)
+        x = torch.ones(1 << 24, device=dev, dtype=torch.float64)
+        t_end = time.perf_counter() + ms_ * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(50):
+                x.mul_(1.0000001)
+            torch.cuda.synchronize(dev)
+        del x
+
+    preheat(a.preheat_ms)
     dt = region(W)                     # THE timed region: W warm-up steps have run, now exactly K steps
 
     st = altro.stats(mp.solver)
@@ -445,6 +463,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "preheat_ms": a.preheat_ms,
             "ms_per_step": 1e3 * dt / K,
             "higher_is_better": True,
             "scaling": "weak",
