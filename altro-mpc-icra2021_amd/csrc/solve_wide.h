@@ -2705,9 +2705,10 @@ __global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel
 
 // One wave per instance unless the LDS carve-up leaves room for a single instance per CU anyway (n >= 48 or so):
 // then three more waves on the CU's other SIMDs share the large products.
-inline int wide_block_threads(int n, int m, size_t lds_bytes) {
-  if (const char* e = getenv("ALTRO_WIDE_COOP"))  // diagnostic switch: 0 = never, 1 = every size with n or m > 16
-    return (atoi(e) != 0 && !(n <= 16 && m <= 16)) ? 256 : 64;
+// coop_mode: -1 = by size (the rule above), 0 = never, 1 = every size with n or m > 16 (diagnostic switch ALTRO_WIDE_COOP,
+// read once when the solver is created)
+inline int wide_block_threads(int n, int m, size_t lds_bytes, int coop_mode = -1) {
+  if (coop_mode >= 0) return (coop_mode != 0 && !(n <= 16 && m <= 16)) ? 256 : 64;
   return (!(n <= 16 && m <= 16) && lds_bytes > 80 * 1024) ? 256 : 64;
 }
 

@@ -57,6 +57,7 @@ struct WideBackend {
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
   unsigned* bwst = nullptr;   // [B][136] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
+  int coop_mode = -1, static_mask = 7;  // ALTRO_WIDE_COOP, ALTRO_WIDE_STATIC_MASK at create time
   int compact_np_max = 48;  // wide_compact: the LDS carve-up with Qux and K inside W, for padded state dimensions up to this
   bool debug_keep_gains = false;  // ALTRO_DEBUG_KEEP_GAINS=1 at create time: stale gains are kept (exists to show that the tests notice them)
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
@@ -112,7 +113,10 @@ struct WideBackend {
     o = *opts;
     device = dev;
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); debug_keep_gains = kg && kg[0] == '1'; }
-    if (const char* e = getenv("ALTRO_WIDE_COMPACT")) compact_np_max = atoi(e);  // diagnostic switch: 0 = never, 32 / 48 / 64 = up to that padded n
+    // diagnostic switches, read once here (never on the launch path)
+    if (const char* e = getenv("ALTRO_WIDE_COMPACT")) compact_np_max = atoi(e);  // 0 = never, 32 / 48 = up to that padded n
+    if (const char* e = getenv("ALTRO_WIDE_COOP")) coop_mode = atoi(e) != 0 ? 1 : 0;  // cooperative blocks: 0 = never, 1 = every size with n or m > 16
+    if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) static_mask = atoi(e);     // which uses of time-invariant constraint tables stay in LDS
     WCHK(hipSetDevice(device));
     const Lds L = lds_layout(d.n, d.m, kMaxP);
     (void)L;
@@ -420,7 +424,7 @@ struct WideBackend {
     p.bcon_istride = con_per_instance ? (size_t)d.N * Pn : 0; p.ctype = ctype; p.rowk0 = rowk0; p.rowk1 = rowk1; p.rowc0 = rowc0; p.rowcp = rowcp; p.ncone = ncone;
     p.con_static = 7;
     for (const auto& bl : blocks) p.con_static = bl.per_knot ? 0 : p.con_static;
-    if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) p.con_static &= atoi(e);  // diagnostic switch
+    p.con_static &= static_mask;
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
@@ -435,7 +439,7 @@ struct WideBackend {
 
   int compact() const {  // only for one-wave blocks: the helper waves of a cooperative block read W while wave 0 writes Qux
     if (!wide_compact(d.n, d.m, ltv, compact_np_max)) return 0;
-    return wide_block_threads(d.n, d.m, (size_t)lds_layout(d.n, d.m, Pn, 1).total * sizeof(double)) == 64 ? 1 : 0;
+    return wide_block_threads(d.n, d.m, (size_t)lds_layout(d.n, d.m, Pn, 1).total * sizeof(double), coop_mode) == 64 ? 1 : 0;
   }
   size_t lds_bytes() const { return (size_t)lds_layout(d.n, d.m, Pn, compact()).total * sizeof(double); }
 
@@ -475,7 +479,7 @@ struct WideBackend {
     WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
     WCHK(hipEventRecord(h0, stream));
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes())), lds_bytes(), stream, params(), mpc, first_step, nsteps);
+    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
     WCHK(hipGetLastError());
     gains_valid = true;  // (until a setter changes something the stored gains depend on)
     WCHK(hipEventRecord(h1, stream));
@@ -495,7 +499,7 @@ struct WideBackend {
     WCHK(hipSetDevice(device));
     int rc = prepare_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes())), lds_bytes(), stream, params(), 2, step, 1);
+    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), 2, step, 1);
     WCHK(hipGetLastError());
     kref = step + 1;
     return ALTRO_OK;
