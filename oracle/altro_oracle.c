@@ -51,6 +51,10 @@ struct orc_solver {
   /* diagnostic (orc_debug_pass_trace): highest knot whose second-order cost expansion differs from the previous pass's */
   int *dbg_buf, dbg_cap, dbg_n;
   double *dbg_prev;
+  /* diagnostic (orc_debug_ls_trace): per rejected line-search trial, the fraction of the knots after which the partial
+   * cost plus a lower bound of the rest already exceeds J_prev (suffix bound, crude bound) and J - J_prev */
+  double *dbg_ls;
+  int dbg_ls_cap, dbg_ls_n;
 };
 
 /* ---------------------------------------------------------------- options */
@@ -172,6 +176,15 @@ void orc_set_opts(orc_solver* s, const orc_opts* o) { s->opts = *o; }
 /* diagnostic: every backward pass from now on appends to buf (up to cap entries) the highest knot whose second-order
  * cost expansion (lxx, luu, lux: the active set and the penalties) differs from the previous pass's, -1 if none does.
  * Returns the number of passes recorded so far and restarts the count. */
+/* diagnostic: rejected line-search trials from now on append 4 doubles each to buf (see dbg_rejected_trial); returns the
+ * number recorded so far and restarts the count */
+int orc_debug_ls_trace(orc_solver* s, double* buf, int cap) {
+  int got = s->dbg_ls_n;
+  s->dbg_ls = buf;
+  s->dbg_ls_cap = cap;
+  s->dbg_ls_n = 0;
+  return got;
+}
 int orc_debug_pass_trace(orc_solver* s, int* buf, int cap) {
   int got = s->dbg_n;
   s->dbg_buf = buf;
@@ -735,6 +748,57 @@ static int rollout_open(orc_solver* s) {
   return 1;
 }
 
+/* diagnostic only: where would a sweep over the knots know that this trial is rejected (J >= J_prev)?  Each AL term is
+ * bounded below by -|lam|^2 / (2 mu), the stage cost by 0. */
+static void dbg_rejected_trial(orc_solver* s, const double* X, const double* U, double J, double J_prev) {
+  int n = s->n, m = s->m, N = s->N;
+  if (!s->dbg_ls || s->dbg_ls_n >= s->dbg_ls_cap) { s->dbg_ls_n++; return; }
+  double* ck = dalloc(N); double* lb = dalloc(N);
+  for (int k = 0; k < N; ++k) {
+    const double* x = X + (size_t)k * n;
+    double l = 0;
+    if (k < N - 1) {
+      const double* u = U + (size_t)k * m;
+      for (int i = 0; i < n; ++i) { double e = x[i] - s->Xref[(size_t)k * n + i]; l += 0.5 * s->Qd[i] * e * e; }
+      for (int i = 0; i < m; ++i) { double e = u[i] - s->Uref[(size_t)k * m + i]; l += 0.5 * s->Rd[i] * e * e; }
+      ck[k] = l * s->dt;
+    } else {
+      for (int i = 0; i < n; ++i) { double e = x[i] - s->Xref[(size_t)k * n + i]; l += 0.5 * s->Qfd[i] * e * e; }
+      ck[k] = l;
+    }
+  }
+  double cv[2 * 64];
+  for (int ci = 0; ci < s->ncon; ++ci) {
+    con_t* c = &s->con[ci];
+    int rows = c->p;
+    for (int k = c->k0; k <= c->k1; ++k) {
+      size_t off = (size_t)(k - c->k0) * rows;
+      con_eval(s, c, k, X + (size_t)k * n, U + (size_t)(k < N - 1 ? k : 0) * m, cv);
+      ck[k] += con_cost(c, cv, c->lam + off, c->mu + off);
+      for (int r = 0; r < rows; ++r) lb[k] -= c->lam[off + r] * c->lam[off + r] / (2.0 * c->mu[off + (c->kind == ORC_SOC ? 0 : r)]);
+    }
+  }
+  double all = 0, suf = 0;
+  for (int k = 0; k < N; ++k) all += lb[k];
+  double part = 0; int x_suf = N, x_crude = N;
+  suf = all;
+  for (int k = 0; k < N; ++k) {
+    part += ck[k]; suf -= lb[k];
+    if (x_suf == N && part + suf > J_prev) x_suf = k + 1;
+    if (x_crude == N && part + all > J_prev) x_crude = k + 1;
+  }
+  /* the same sweep from the last knot down (o[3]) */
+  int x_rev = N;
+  part = 0; suf = all;
+  for (int k = N - 1; k >= 0; --k) {
+    part += ck[k]; suf -= lb[k];
+    if (x_rev == N && part + suf > J_prev) x_rev = N - k;
+  }
+  double* o = s->dbg_ls + 4 * (size_t)s->dbg_ls_n++;
+  o[0] = (double)x_suf / N; o[1] = (double)x_crude / N; o[2] = J - J_prev; o[3] = (double)x_rev / N;
+  free(ck); free(lb);
+}
+
 /* forwardpass!  (P7).  Line search on alpha = 1, 1/2, ...  [PKG] */
 static double forward_pass(orc_solver* s, const double dV[2], double J_prev, double* alpha_out, double* cmax_out) {
   const orc_opts* o = &s->opts;
@@ -753,6 +817,7 @@ static double forward_pass(orc_solver* s, const double dV[2], double J_prev, dou
     }
     if (!rollout_alpha(s, alpha)) { iter++; alpha /= 2.0; continue; }
     J = total_cost(s, s->Xb, s->Ub, &cmax);
+    if (s->dbg_ls && J >= J_prev) dbg_rejected_trial(s, s->Xb, s->Ub, J, J_prev);
     expected = -alpha * (dV[0] + alpha * dV[1]);
     z = expected > 0.0 ? (J_prev - J) / expected : -1.0;
     iter++;

@@ -130,7 +130,8 @@ void orc_set_reference(orc_solver* s, const double* Xref, const double* Uref);
 void orc_set_initial_state(orc_solver* s, const double* x0);
 void orc_set_controls(orc_solver* s, const double* U);
 void orc_set_opts(orc_solver* s, const orc_opts* o);
-int orc_debug_pass_trace(orc_solver* s, int* buf, int cap);   /* diagnostic, see altro_oracle.c */
+int orc_debug_pass_trace(orc_solver* s, int* buf, int cap);
+int orc_debug_ls_trace(orc_solver* s, double* buf, int cap);   /* diagnostic, see altro_oracle.c */
 
 /* Returns constraint id.  k_first..k_last are 0-based inclusive knots (knot N-1 is terminal:
  * only state columns are used there).
