@@ -49,7 +49,7 @@
 #define ALTRO_PD_CLOSED 4  // knots of prefetch in the closed-loop rollout (2..8 measured with the butterfly gain sums: 4 best)
 #endif
 #ifndef ALTRO_PD_ADJOINT
-#define ALTRO_PD_ADJOINT 8  // knots of prefetch in the costate sweep (one load per knot)
+#define ALTRO_PD_ADJOINT 13  // knots per group of the costate sweep (one load per knot, two register sets: see adjoint())
 #endif
 #ifndef ALTRO_PD_FOSWEEP
 #define ALTRO_PD_FOSWEEP 4  // knots of prefetch in the first-order sweep (2 + NU loads per knot)
@@ -1705,22 +1705,32 @@ struct Solver {
     const int N = P.N;
     bool gbig = false;
     double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
-    constexpr int PD = ALTRO_PD_ADJOINT;
-    double rq[PD];
-    sfor<0, PD>([&](auto u) { rq[decltype(u)::value] = ldg(P.Qz, at(imax(N - 2 - decltype(u)::value, 0))); });
-    const int ngroups = (N - 1 + PD - 1) / PD;
+    // Two register sets of H knots each: the loads of group g + 1 are issued BEFORE group g is consumed.  A ring (reload slot
+    // U right after knot U) looked like H knots of lead time but was not: hipcc places ONE s_waitcnt at the top of the loop
+    // body that waits for every load of the ring except the youngest (vmcnt(1) with eight in flight), i.e. for loads issued a
+    // knot ago -- a full memory round trip per group (22 k cycles per sweep of 49 knots where the issue is 8 k).  Here the
+    // same conservative wait asks for exactly what is needed: everything but the H loads just issued.
+    constexpr int H = ALTRO_PD_ADJOINT;
+    double ra[H], rb[H];
     int k = N - 2;
-    for (int gq = 0; gq < ngroups; ++gq, k -= PD) {  // body: one basic block
-      sfor<0, PD>([&](auto u) {
+    sfor<0, H>([&](auto u) { ra[decltype(u)::value] = ldg(P.Qz, at(imax(k - decltype(u)::value, 0))); });
+    auto group = [&](double (&cur_)[H], double (&nxt)[H]) {
+      sfor<0, H>([&](auto u) { nxt[decltype(u)::value] = ldg(P.Qz, at(imax(k - H - decltype(u)::value, 0))); });
+      sfor<0, H>([&](auto u) {
         constexpr int U = decltype(u)::value;
         const bool valid = k - U >= 0;
-        double acc4[4] = {rq[U], 0.0, 0.0, 0.0};
+        double acc4[4] = {cur_[U], 0.0, 0.0, 0.0};
         Blk<NX, NU>::GTS(acc4, sv, g);
         const double gz = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);  // x lanes: lambda_k, u lanes: g_k
         gbig = gbig | (valid & is_u & !(fabs(gz) <= thr));
         sv = valid ? (is_x ? gz : 0.0) : sv;
-        rq[U] = ldg(P.Qz, at(imax(k - U - PD, 0)));
       });
+      k -= H;
+    };
+    while (k >= 0) {  // body: two groups, one basic block each
+      group(ra, rb);
+      if (k < 0) break;
+      group(rb, ra);
     }
     gtiny = !row_any(gbig, lane);
     prio_base();
