@@ -58,6 +58,7 @@ struct altro_handle {
   int mpc_shift = 1;
   int reuse = 1;  // gain reuse (solve_dpp16.h fosweep); ALTRO_NO_REUSE=1 at create time switches it off (tests)
   int lone = 1;  // backward_lone (solve_dpp16.h); ALTRO_NO_LONE=1 at create time switches it off (tests: lone == four-row pass bit for bit)
+  int shadow = 1;  // ALTRO_NO_SHADOW=1 at create time: rows that sit a phase out keep their own instance (solve_dpp16.h shadow_enter)
   int* cur = nullptr;
   int *perm = nullptr, *gscore = nullptr;  // [Bp] wave slot -> instance of a grouped MPC launch, and its sort key
   bool debug_keep_gains = false;           // ALTRO_DEBUG_KEEP_GAINS=1 at create time: the setters do NOT drop the stored gains (exists
@@ -434,7 +435,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.shadow = h->shadow; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
   p.Dff = h->Dff; p.ahash = h->ahash; p.kmu = h->kmu; p.n_fo = h->n_fo;
   p.Qz = h->Qz;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.ckn = h->ckn; p.con_inv = h->con_inv;
@@ -632,6 +633,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
     { const char* nl = getenv("ALTRO_NO_LONE"); h->lone = (nl && nl[0] == '1') ? 0 : 1; }
+    { const char* nsh = getenv("ALTRO_NO_SHADOW"); h->shadow = (nsh && nsh[0] == '1') ? 0 : 1; }
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
     { const char* dw = getenv("ALTRO_DEBUG_TRACE_WAVE"); h->dbg_wave = dw ? atoi(dw) : -1; }
     { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }

@@ -127,6 +127,7 @@ struct SolveParams {
   int dbg_wave;          // -DALTRO_PHASE_STAMPS builds: the wave whose turns are traced behind the wave_cycles records
   int resync;            // 1: rows wait a turn to stay in step with their wave-mates (run(), phase A)
   int reuse;             // 1: gain reuse (fosweep) allowed; ALTRO_NO_REUSE=1 at create time switches it off
+  int shadow;  // rows that sit a phase out take the identity of a row that takes part (Solver::shadow_enter)
   int lone;              // 1: a backward pass that only one row of a wave needs runs spread over the four DPP rows (backward_lone)
   // generic affine constraints (LINEAR eq/ineq, SOC): up to 16 constraint rows per knot, row r
   // on lane r, organised in 4 quads of 4 lanes; a quad is one cone (SOC of dimension <= 4, or
@@ -1466,6 +1467,26 @@ struct Solver {
     sm = c.sm;
     ah = c.ah;
   }
+  // Shadow rows.  The four rows of a wave run every phase together, and a row that sits a phase out used to run it on its
+  // own instance: real loads of operands nobody needs (a fifth of the kernel's HBM traffic).  It now takes the identity of a
+  // row that does take part, exactly as in a lone phase: its loads hit the lines that row loads in the same instruction,
+  // and what it stores is either that row's values over again (same inputs, same instructions) or goes to that row's
+  // trash slots (its own flags still say "not mine").  Results cannot change: the caller reads a phase's outputs only for
+  // the rows that asked for it.
+  __device__ __forceinline__ LoneCtx shadow_enter(bool active) {
+    LoneCtx c{inst, rowoff, rs, sm, ah};
+    if (P.shadow == 0) return c;
+    const unsigned long long bm = __ballot(active);
+    if (bm == 0ull) return c;
+    const int lrow = first_row(bm);  // wave-uniform: a row that takes part
+    const int li = __builtin_amdgcn_readlane(inst, lrow * LW);
+    inst = active ? inst : li;
+    rowoff = active ? rowoff : (unsigned)li * LW + j;
+    rs = active ? rs : c.rs - (lane >> 4) + lrow;
+    sm = active ? sm : c.sm - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
+    ah = active ? ah : c.ah - lane + lrow * LW + j;
+    return c;
+  }
   // the row of the wave (0..3) a wave-uniform ballot of a per-row flag names, and how many rows it names
   static __device__ __forceinline__ int rows_in(unsigned long long b) {
     return (int)((b & 1ull) + ((b >> 16) & 1ull) + ((b >> 32) & 1ull) + ((b >> 48) & 1ull));
@@ -1854,7 +1875,11 @@ struct Solver {
         if (wave_any(begin)) {
           const int stp = rs->step;
           const bool go = begin && (stp < (mpc ? nsteps : 1));
-          if (mpc && wave_any(go)) plant_step(go, first_step + stp);
+          if (mpc && wave_any(go)) {
+            const LoneCtx sh = shadow_enter(go);
+            plant_step(go, first_step + stp);
+            lone_leave(sh);
+          }
           if (o.reset_duals && !P.prepare_only && wave_any(go)) {  // initialize!: lambda <- 0
             for (int k = P.box_k0; k <= P.box_k1; ++k) {
               stg(P.Lb, lb_at((go & bounded) ? k : P.N, 0), 0.0);
@@ -1891,7 +1916,10 @@ struct Solver {
         const bool ob = rs->phase == PH_OUTER_BEGIN;
         if (wave_any(ob)) {
           ALTRO_STAMP(long long ts = stamp();)
-          const RollOut r0 = rollout<true>(ob, ob && rs->shift != 0, ob);
+          const bool ob_shift = ob && rs->shift != 0;
+          const LoneCtx sh = shadow_enter(ob);
+          const RollOut r0 = rollout<true>(ob, ob_shift, ob);
+          lone_leave(sh);
           ALTRO_STAMP(t_ro += stamp() - ts;)
           if (ob) {
             const int outer = rs->outer;
@@ -1968,7 +1996,9 @@ struct Solver {
             if (wave_any(tryg)) {
               bool gt;
               ALTRO_STAMP(long long ts = stamp();)
+              const LoneCtx sh = shadow_enter(tryg);
               adjoint(gt);
+              lone_leave(sh);
               ALTRO_STAMP(t_aj += stamp() - ts; c_aj++;)
               gconf = tryg && gt;
             }
@@ -1979,7 +2009,9 @@ struct Solver {
               double f1, f2;
               bool ft;
               ALTRO_STAMP(long long ts = stamp();)
+              const LoneCtx sh = shadow_enter(fo);
               fosweep(fo, f1, f2, ft);
+              lone_leave(sh);
               ALTRO_STAMP(t_fo += stamp() - ts; c_fo++;)
               if (fo) {
                 dV1 = f1;
@@ -2016,6 +2048,7 @@ struct Solver {
             } else {
               double b1, b2;
               bool bt;
+              const LoneCtx sh = shadow_enter(bwrow);
               if (o.strict) {
                 if (with_rho) backward<true, true>(b1, b2, fail, bt, bwrow);
                 else backward<false, true>(b1, b2, fail, bt, bwrow);
@@ -2023,6 +2056,7 @@ struct Solver {
                 if (with_rho) backward<true, false>(b1, b2, fail, bt, bwrow);
                 else backward<false, false>(b1, b2, fail, bt, bwrow);
               }
+              lone_leave(sh);
               if (bwrow) {
                 dV1 = b1;
                 dV2 = b2;
@@ -2104,7 +2138,9 @@ struct Solver {
           };
           if (wave_any(searching)) {
             ALTRO_STAMP(long long ts = stamp();)
+            const LoneCtx sh = shadow_enter(searching);
             const RollOut rr = rollout<false>(true, false, searching);
+            lone_leave(sh);
             ALTRO_STAMP(t_rc += stamp() - ts; c_rc++;)
             if (searching) {
               rs->nro += 1;
@@ -2212,7 +2248,9 @@ struct Solver {
           double grad = confirm ? 0.0 : __builtin_inf();
           if (wave_any(cand && !confirm)) {
             ALTRO_STAMP(long long ts = stamp();)
+            const LoneCtx sh = shadow_enter(cand && !confirm);
             grad = todorov();
+            lone_leave(sh);
             ALTRO_STAMP(t_td += stamp() - ts;)
           }
           if (inner) {
@@ -2266,7 +2304,9 @@ struct Solver {
       __builtin_amdgcn_wave_barrier();
       if (wave_any(upd)) {
         ALTRO_STAMP(long long ts = stamp();)
+        const LoneCtx sh = shadow_enter(upd);
         dual_update(upd);
+        lone_leave(sh);
         ALTRO_STAMP(t_du += stamp() - ts;)
         if (upd) rs->mu = fmin(fmax(phi * rs->mu, 0.0), o.penalty_max);
       }
