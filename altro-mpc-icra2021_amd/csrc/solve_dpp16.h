@@ -1342,19 +1342,21 @@ struct Solver {
     struct In {
       double qz, z, kr[NU];
     };
-    In ring[PD];
     auto load = [&](int k, In& in) {
       in.qz = ldg(P.Qz, at(k));
       in.z = ldg(P.Z, zs + at(k));
       sfor<0, NU>([&](auto a) { in.kr[decltype(a)::value] = ldg(P.KD, kd_at(k, decltype(a)::value)); });
     };
-    sfor<0, PD>([&](auto u) { load(imax(N - 2 - decltype(u)::value, 0), ring[decltype(u)::value]); });
-    const int ngroups = (N - 1 + PD - 1) / PD;
+    // two register sets of PD knots: the operands of the next group are requested before the current one is consumed (see
+    // adjoint(): a reload-after-use ring has no lead time for the loads of a loop body's last knots)
+    In ra[PD], rb[PD];
     int k = N - 2;
-    for (int gq = 0; gq < ngroups; ++gq, k -= PD) {  // body: one basic block
+    sfor<0, PD>([&](auto u) { load(imax(k - decltype(u)::value, 0), ra[decltype(u)::value]); });
+    auto group = [&](In (&cur_)[PD], In (&nxt)[PD]) {
+      sfor<0, PD>([&](auto u) { load(imax(k - PD - decltype(u)::value, 0), nxt[decltype(u)::value]); });
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        const In& in = ring[U];
+        const In& in = cur_[U];
         const bool valid = k - U >= 0;
         double acc4[4] = {in.qz, 0.0, 0.0, 0.0};
         Blk<NX, NU>::GTS(acc4, sv, g);
@@ -1397,8 +1399,13 @@ struct Solver {
         dV2 += valid ? -0.5 * t1 : 0.0;
         stg(P.Dff, at((live & valid) ? k - U : N), dl);
         sv = valid ? (is_x ? snew : 0.0) : sv;
-        load(imax(k - U - PD, 0), ring[U]);
       });
+      k -= PD;
+    };
+    while (k >= 0) {  // body: two groups
+      group(ra, rb);
+      if (k < 0) break;
+      group(rb, ra);
     }
     dtiny = !row_any(dbig, lane);
     prio_base();

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of two (or more) diagnostic builds on ONE box, alternating: tools/debug/gpu_ab_libs.sh libA.so libB.so [steps]
-S=${3:-20}
+# A/B of diagnostic builds on ONE box, alternating, twice over: tools/debug/gpu_ab_libs.sh STEPS libA.so libB.so ...
+S=$1; shift
 for rep in 1 2; do
-  for lib in "$1" "$2"; do
+  for lib in "$@"; do
     echo "== $lib"
-    ALTRO_HIP_LIB=$lib python tools/gpu_makespan.py $S | grep -E "wave cycles|mean wave|kernel ms|each"
+    ALTRO_HIP_LIB=$lib python tools/gpu_makespan.py $S | grep -E "wave cycles|kernel ms|first-order"
   done
 done
