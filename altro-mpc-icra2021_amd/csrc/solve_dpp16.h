@@ -550,24 +550,27 @@ struct Solver {
   static __device__ __forceinline__ double lane_cost_grad(const LaneConst& c, double mu, double z, double zr, double w,
                                                           double lhi, double llo, bool box_on, double& viol, double& qz,
                                                           unsigned& code) {
+    // A side that is absent (no bound on this element, or a knot outside the box range) is switched off at its INPUTS --
+    // value -1 (inside), dual 0 -- instead of at its four outputs: the side is then inactive, its cost and gradient terms
+    // are exact zeros and its violation candidate is negative.  Three selects per side instead of five (the duals may
+    // come in unselected); the arithmetic of a side that is present is unchanged.
     const double e = z - zr;
     double Jl = 0.5 * w * e * e;
-    const double chi = z - c.zmax, clo = c.zmin - z;
-    const bool ahi = (chi >= 0.0) | (lhi > 0.0);
-    const bool alo = (clo >= 0.0) | (llo > 0.0);
-    const double phi = ahi ? mu * chi : 0.0, plo = alo ? mu * clo : 0.0;
-    const double Jhi = lhi * chi + 0.5 * phi * chi;
-    const double Jlo = llo * clo + 0.5 * plo * clo;
     const bool bh = box_on & c.has_hi, bl = box_on & c.has_lo;
-    Jl += bh ? Jhi : 0.0;
-    Jl += bl ? Jlo : 0.0;
-    viol = fmax(viol, bh ? chi : 0.0);
-    viol = fmax(viol, bl ? clo : 0.0);
+    const double chi = bh ? z - c.zmax : -1.0, clo = bl ? c.zmin - z : -1.0;
+    const double lh = bh ? lhi : 0.0, ll = bl ? llo : 0.0;
+    const bool ahi = (chi >= 0.0) | (lh > 0.0);
+    const bool alo = (clo >= 0.0) | (ll > 0.0);
+    const double phi = ahi ? mu * chi : 0.0, plo = alo ? mu * clo : 0.0;
+    Jl += lh * chi + 0.5 * phi * chi;
+    Jl += ll * clo + 0.5 * plo * clo;
+    viol = fmax(viol, chi);   // viol >= 0 on entry
+    viol = fmax(viol, clo);
     if constexpr (GRAD) {
       qz = w * e;
-      qz += bh ? (lhi + phi) : 0.0;
-      qz -= bl ? (llo + plo) : 0.0;
-      code = ((bh & ahi) ? 1u : 0u) | ((bl & alo) ? 2u : 0u);
+      qz += lh + phi;
+      qz -= ll + plo;
+      code = (ahi ? 1u : 0u) | (alo ? 2u : 0u);
     }
     return Jl;
   }
@@ -694,7 +697,13 @@ struct Solver {
           // lane^2 (afterwards every lane of a quad holds the quad's part of row (l&3)-NX), then the
           // four quads are added by two rotations.  Lane NX + A ends with sum_j K[A][j] dx_j.
           double p[4];
-          sfor<0, 4>([&](auto c) { p[decltype(c)::value] = kval[decltype(c)::value] ? in.kcol[decltype(c)::value] * dx : 0.0; });
+          if constexpr (NU == 4 && NZ == LW) {
+            // every slot is a gain row and every lane an element: dx is already 0 on the control lanes, whose slots hold
+            // the (finite) factors of Quu, so the products there are exact zeros without a select
+            sfor<0, 4>([&](auto c) { p[decltype(c)::value] = in.kcol[decltype(c)::value] * dx; });
+          } else {
+            sfor<0, 4>([&](auto c) { p[decltype(c)::value] = kval[decltype(c)::value] ? in.kcol[decltype(c)::value] * dx : 0.0; });
+          }
           const double n0 = p[0] + dpp_mov<DPP_XOR1>(p[1]);
           const double n2 = p[2] + dpp_mov<DPP_XOR1>(p[3]);
           double q = n0 + dpp_mov<DPP_XOR2>(n2);
@@ -726,7 +735,7 @@ struct Solver {
       if constexpr (!CONES) {
         double qz;
         unsigned code;
-        Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol, qz, code);
+        Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, OPEN ? lhi : in.lhi, OPEN ? llo : in.llo, bx, viol, qz, code);
         qh = hash_add(qh, code, k);
         stg(P.Qz, at(storeq ? k : N), qz);
       } else {

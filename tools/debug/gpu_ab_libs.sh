@@ -4,6 +4,6 @@ S=$1; shift
 for rep in 1 2; do
   for lib in "$@"; do
     echo "== $lib"
-    ALTRO_HIP_LIB=$lib python tools/gpu_makespan.py $S | grep -E "wave cycles|kernel ms|first-order"
+    ALTRO_HIP_LIB=$lib python tools/gpu_makespan.py $S | grep -E "wave cycles|kernel ms|each"
   done
 done
