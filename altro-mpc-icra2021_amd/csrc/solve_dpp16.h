@@ -620,7 +620,9 @@ struct Solver {
     });
     const double fv = ldg(P.fvec, rowoff);
     double xb = ldg(P.x0, rowoff);
-    double Jacc = 0.0, viol = 0.0;
+    // The stage costs are summed in FOUR classes of knots (k mod 4), each in ascending order, and combined as
+    // (J0 + J1) + (J2 + J3) + terminal: rollout_lone(), where DPP row r evaluates exactly class r, gives the same bits.
+    double Jcls[4] = {0.0, 0.0, 0.0, 0.0}, Jterm = 0.0, viol = 0.0;
     bool limit = false, changed = false, big = false;
     AHash qh = {0u, 0u};
     const int k1 = P.box_k1;
@@ -677,7 +679,9 @@ struct Solver {
       }
     };
 
-    auto stage = [&](int k, const KnotIn& in, const ConK& ck) {
+    auto stage = [&](auto cls_, int k, const KnotIn& in, const ConK& ck) {
+      // the callers pass the knot's position in its group of PD = 4 or 8: k mod 4 (conic kernels: one sum, as before)
+      double& Jacc = Jcls[CONES ? 0 : (decltype(cls_)::value & 3)];
       const bool bx = box_at(k);
       const double lhi = bx ? in.lhi : 0.0, llo = bx ? in.llo : 0.0;
       double zb;
@@ -783,7 +787,7 @@ struct Solver {
     for (int g = 0; g < ngroups; ++g, k += PD) {
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        stage(k + U, ring[U], cring[U]);
+        stage(u, k + U, ring[U], cring[U]);
         load(imin(k + U + PD, N - 2), ring[U], cring[U]);
       });
     }
@@ -791,7 +795,7 @@ struct Solver {
       const int rem = (N - 1) - k;
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
-        if (U < rem) stage(k + U, ring[U], cring[U]);
+        if (U < rem) stage(u, k + U, ring[U], cring[U]);
       });
     }
     {  // terminal knot: state only
@@ -802,17 +806,17 @@ struct Solver {
       if constexpr (!CONES) {
         double qz;
         unsigned code;
-        Jacc += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
+        Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
         qh = hash_add(qh, code, kt);
         stg(P.Qz, at(storeq ? kt : N), is_x ? qz : 0.0);
       } else {
-        Jacc += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
+        Jcls[0] += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
       }
       if constexpr (CONES) {
         const bool act = con_act(t_ck.cm, kt);
         const double v = con_value(zb, t_ck.arow, t_ck.brow);
         const ConeEval e = cone_eval<false>(v, act ? t_lc : 0.0, mu, t_ck.cm, act, dmax, so2);
-        Jacc += e.cost;
+        Jcls[0] += e.cost;
         viol = fmax(viol, e.viol);
       }
       limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
@@ -822,12 +826,228 @@ struct Solver {
       }
     }
     RollOut r;
-    r.J = row_sum(Jacc);
+    if constexpr (CONES) r.J = row_sum(Jcls[0]);
+    else r.J = ((row_sum(Jcls[0]) + row_sum(Jcls[1])) + (row_sum(Jcls[2]) + row_sum(Jcls[3]))) + row_sum(Jterm);
     r.cmax = row_max(viol);
     r.limit = row_any(limit, lane);
     r.unchanged = !row_any(changed, lane);
     r.tiny = !row_any(big, lane);
     r.qh = qh;
+    prio_base();
+    return r;
+  }
+
+  // Lone rollouts (box-only kernels).  When ONE row of the wave needs a rollout -- the tail of a launch, where single hard
+  // instances walk their chains alone -- the other three rows used to execute it as shadows.  A rollout knot is ~45
+  // instructions of recurrence (z_k -> x_{k+1}) and ~110 that hang off it (cost, gradient, violation, active-set hash,
+  // stores): here all four rows run the recurrence of a group of four knots (they are clones of the lone row: same
+  // operands, same results), then DPP row r does the rest for knot k0 + r alone.  Per knot ~90 (closed loop) and ~55
+  // (open loop) instructions instead of 169 and 154.  Row r sums exactly class r of rollout()'s stage costs and the
+  // classes are combined in rollout()'s order, so both forms return the same bits (test: ALTRO_NO_LONE=1).
+  // The caller has pointed inst / rowoff / rs of all lanes at the lone row (lone_enter); take = storeq = true.
+  template <bool OPEN>
+  __device__ RollOut rollout_lone() {
+    static_assert(!CONES, "box-only kernels");
+    phase_begin();
+    prio_serial();
+    const LaneConst lc = consts();
+    const double mu = rs->mu;
+    const int cur = rs->cur, kref = rs->kref;
+    const bool shift = OPEN && (rs->shift != 0);
+    const int rr = lane >> 4;
+    const unsigned zs = plane(cur);
+    const unsigned zd = OPEN ? plane(cur) : plane(cur ^ 1);
+    const int N = P.N;
+    double grow[NZ];
+    sfor<0, NZ>([&](auto c) {
+      constexpr int C = decltype(c)::value;
+      grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
+    });
+    const double fv = ldg(P.fvec, rowoff);
+    double xb = ldg(P.x0, rowoff);
+    double Jc = 0.0, Jterm = 0.0, viol = 0.0;
+    bool limit = false, changed = false, big = false;
+    AHash qh = {0u, 0u};
+    const int k1 = P.box_k1;
+    const bool shu = shift && !is_x;     // controls are read one knot ahead
+    const bool wl = shift && bounded;    // shifted duals are written back
+    double lim = is_x ? P.o.max_state_value : P.o.max_control_value;
+    asm volatile("" : "+v"(lim));
+    unsigned kofs[4] = {0u, 0u, 0u, 0u};
+    bool kval[4] = {false, false, false, false};
+    if constexpr (!OPEN && NU <= 4) {  // slot order of the gain rows: see rollout()
+      sfor<0, 4>([&](auto c) {
+        constexpr int S = decltype(c)::value;
+        const int A = ((S ^ (j & 3)) - NX) & 3;
+        kval[S] = is_x & (A < NU);
+        kofs[S] = (unsigned)imin(A, NU - 1) * LW;
+      });
+    }
+    constexpr int KS = (NU <= 4) ? 4 : NU;
+    struct Rec {  // operands of the recurrence of four knots: the same for every row
+      double z[4], kcol[OPEN ? 1 : 4][OPEN ? 1 : KS], dff[OPEN ? 1 : 4];
+    };
+    struct Cst {  // operands of the cost terms of this row's knot of the group
+      double zr, lhi, llo;
+    };
+    auto load_rec = [&](int k0, Rec& r) {
+      sfor<0, 4>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        const int ku = imin(k0 + U, N - 2);
+        r.z[U] = ldg(P.Z, zs + at(shu ? imin(ku + 1, N - 2) : ku));
+        if constexpr (!OPEN) {
+          if constexpr (NU <= 4) {
+            sfor<0, 4>([&](auto c) { r.kcol[U][decltype(c)::value] = ldg(P.KD, kd_at(ku, 0) + kofs[decltype(c)::value]); });
+          } else {
+            sfor<0, NU>([&](auto c) { r.kcol[U][decltype(c)::value] = ldg(P.KD, kd_at(ku, decltype(c)::value)); });
+          }
+          r.dff[U] = ldg(P.Dff, at(ku));
+        }
+      });
+    };
+    auto load_cst = [&](int k0, Cst& c) {
+      const int kq = imin(k0 + rr, N - 2);
+      c.zr = ldg(P.Zref, at(kref + kq));
+      const int kk = shift ? imax(imin(kq + 1, k1), 0) : kq;
+      c.lhi = ldg(P.Lb, lb_at(kk, 0));
+      c.llo = ldg(P.Lb, lb_at(kk, 1));
+    };
+    auto group = [&](int k0, const Rec& r, const Cst& c) {
+      double zb[4];
+      sfor<0, 4>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        const bool valid = k0 + U < N - 1;
+        double zbu;
+        if constexpr (OPEN) {
+          zbu = is_x ? xb : r.z[U];
+        } else {
+          const double dx = is_x ? (xb - r.z[U]) : 0.0;
+          double du;
+          if constexpr (NU <= 4) {
+            double p[4];
+            if constexpr (NU == 4 && NZ == LW) {
+              sfor<0, 4>([&](auto cc) { p[decltype(cc)::value] = r.kcol[U][decltype(cc)::value] * dx; });
+            } else {
+              sfor<0, 4>([&](auto cc) { p[decltype(cc)::value] = kval[decltype(cc)::value] ? r.kcol[U][decltype(cc)::value] * dx : 0.0; });
+            }
+            const double n0 = p[0] + dpp_mov<DPP_XOR1>(p[1]);
+            const double n2 = p[2] + dpp_mov<DPP_XOR1>(p[3]);
+            double q = n0 + dpp_mov<DPP_XOR2>(n2);
+            q += dpp_mov<DPP_ROR8>(q);
+            q += dpp_mov<DPP_ROR4>(q);
+            du = q;
+          } else {
+            double prod[NU], acc[NU][3];
+            sfor<0, NU>([&](auto a) {
+              constexpr int A = decltype(a)::value;
+              prod[A] = is_x ? r.kcol[U][A] * dx : 0.0;
+              acc[A][0] = acc[A][1] = acc[A][2] = 0.0;
+            });
+            const double one = 1.0;
+            Blk<NX, NU>::KDXT(acc, prod, one);
+            du = (acc[0][0] + acc[0][1]) + acc[0][2];
+            sfor<1, NU>([&](auto a) {
+              constexpr int A = decltype(a)::value;
+              const double da = (acc[A][0] + acc[A][1]) + acc[A][2];
+              du = (j == NX + A) ? da : du;
+            });
+          }
+          const double ub = r.z[U] + du + r.dff[U];  // alpha = 1
+          zbu = is_x ? xb : ub;
+        }
+        zb[U] = zbu;
+        double acc4[4] = {fv, 0.0, 0.0, 0.0};
+        Blk<NX, NU>::GZ(acc4, zbu, grow);
+        const double xn = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        xb = valid ? xn : xb;
+      });
+      // this row's knot of the group
+      const int kq = k0 + rr;
+      const bool valid = kq < N - 1;
+      double zm = zb[0], zo = r.z[0];
+      sfor<1, 4>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        zm = (rr == U) ? zb[U] : zm;
+        zo = (rr == U) ? r.z[U] : zo;
+      });
+      const bool bx = box_at(kq) & valid;
+      const double lhi = bx ? c.lhi : 0.0, llo = bx ? c.llo : 0.0;
+      if constexpr (OPEN) {
+        stg(P.Z, at(valid ? cur * N + kq : 2 * N), zm);
+        const int kl_ = (wl & valid) ? kq : P.N;  // knot N of Lb is the trash row
+        stg(P.Lb, lb_at(kl_, 0), lhi);
+        stg(P.Lb, lb_at(kl_, 1), llo);
+      } else {
+        stg(P.Z, valid ? zd + at(kq) : trash_z(), zm);
+        changed = changed | (valid & (is_x | is_u) & (zm != zo));
+        big = big | (valid & (is_x | is_u) & !(fabs(zm - zo) <= 1e-7 * (1.0 + fabs(zo))));
+      }
+      double qz;
+      unsigned code;
+      // an invalid knot (past the last stage knot) contributes exact zeros: weight 0, box off
+      Jc += lane_cost_grad<true>(lc, mu, zm, c.zr, valid ? lc.wd : 0.0, lhi, llo, bx, viol, qz, code);
+      qh = hash_add(qh, code, kq);
+      stg(P.Qz, at(valid ? kq : N), qz);
+      limit = limit | (valid & (is_x | is_u) & !(fabs(zm) <= lim));
+    };
+
+    // terminal-knot operands (independent of the pipeline)
+    const int kt = N - 1;
+    const double t_zr = ldg(P.Zref, at(kref + kt));
+    const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
+    double t_z = 0.0;
+    if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
+
+    // two register sets: the operands of the next group are requested before the current one is consumed
+    Rec ra, rb;
+    Cst ca, cb;
+    load_rec(0, ra);
+    load_cst(0, ca);
+    int k0 = 0;
+    while (true) {
+      load_rec(k0 + 4, rb);
+      load_cst(k0 + 4, cb);
+      group(k0, ra, ca);
+      k0 += 4;
+      if (k0 >= N - 1) break;
+      load_rec(k0 + 4, ra);
+      load_cst(k0 + 4, ca);
+      group(k0, rb, cb);
+      k0 += 4;
+      if (k0 >= N - 1) break;
+    }
+    {  // terminal knot: state only (every row, redundantly)
+      const bool bx = box_at(kt);
+      const double zb = is_x ? xb : 0.0;
+      if constexpr (OPEN) stg(P.Z, at(cur * N + kt), zb);
+      else stg(P.Z, zd + at(kt), zb);
+      double qz;
+      unsigned code;
+      Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
+      if (rr == 0) qh = hash_add(qh, code, kt);   // once: the rows' partial hashes are added below
+      stg(P.Qz, at(kt), is_x ? qz : 0.0);
+      limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
+      if constexpr (!OPEN) {
+        changed = changed | (is_x & (zb != t_z));
+        big = big | (is_x & !(fabs(zb - t_z) <= 1e-7 * (1.0 + fabs(t_z))));
+      }
+    }
+    RollOut r;
+    r.J = rows_sum4(row_sum(Jc)) + row_sum(Jterm);
+    r.cmax = rows_max4(row_max(viol));
+    r.limit = wave_any(limit);
+    r.unchanged = !wave_any(changed);
+    r.tiny = !wave_any(big);
+    {  // the hash of the whole trajectory: sum of the rows' partial sums (mod 2^32)
+      double o[4];
+      rows_gather(__hiloint2double((int)qh.b, (int)qh.a), o);
+      unsigned a = 0u, b = 0u;
+      sfor<0, 4>([&](auto q) {
+        a += (unsigned)__double2loint(o[decltype(q)::value]);
+        b += (unsigned)__double2hiint(o[decltype(q)::value]);
+      });
+      r.qh = AHash{a, b};
+    }
     prio_base();
     return r;
   }
@@ -1933,9 +2153,21 @@ struct Solver {
         if (wave_any(ob)) {
           ALTRO_STAMP(long long ts = stamp();)
           const bool ob_shift = ob && rs->shift != 0;
-          const LoneCtx sh = shadow_enter(ob);
-          const RollOut r0 = rollout<true>(ob, ob_shift, ob);
-          lone_leave(sh);
+          const unsigned long long bmo = __ballot(ob);
+          RollOut r0;
+          bool lone_ro = false;
+          if constexpr (!CONES) lone_ro = (P.lone != 0) && rows_in(bmo) == 1;
+          if (lone_ro) {  // one row begins a solve: its rollout runs over all four DPP rows (rollout_lone)
+            if constexpr (!CONES) {
+              const LoneCtx ctx = lone_enter(first_row(bmo));
+              r0 = rollout_lone<true>();
+              lone_leave(ctx);
+            }
+          } else {
+            const LoneCtx sh = shadow_enter(ob);
+            r0 = rollout<true>(ob, ob_shift, ob);
+            lone_leave(sh);
+          }
           ALTRO_STAMP(t_ro += stamp() - ts;)
           if (ob) {
             const int outer = rs->outer;
@@ -2154,9 +2386,21 @@ struct Solver {
           };
           if (wave_any(searching)) {
             ALTRO_STAMP(long long ts = stamp();)
-            const LoneCtx sh = shadow_enter(searching);
-            const RollOut rr = rollout<false>(true, false, searching);
-            lone_leave(sh);
+            const unsigned long long bms = __ballot(searching);
+            RollOut rr;
+            bool lone_ro = false;
+            if constexpr (!CONES) lone_ro = (P.lone != 0) && rows_in(bms) == 1;
+            if (lone_ro) {
+              if constexpr (!CONES) {
+                const LoneCtx ctx = lone_enter(first_row(bms));
+                rr = rollout_lone<false>();
+                lone_leave(ctx);
+              }
+            } else {
+              const LoneCtx sh = shadow_enter(searching);
+              rr = rollout<false>(true, false, searching);
+              lone_leave(sh);
+            }
             ALTRO_STAMP(t_rc += stamp() - ts; c_rc++;)
             if (searching) {
               rs->nro += 1;
