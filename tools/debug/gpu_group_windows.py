@@ -1,0 +1,27 @@
+"""Is grouping the instances of a fused launch (ALTRO_NO_GROUP) a gain in every window of the closed loop, or only in the one
+bench.py times first?  20-step launches starting at steps 5, 25, 45, ... of the same loops, each right after 200 steps of a
+scratch copy of the batch (clocks up); kernel ms of the launch with and without grouping (separate processes)."""
+import sys, os, subprocess
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+if len(sys.argv) > 1:
+    import numpy as np
+    import altro_amd_loader
+    import altro_mpc_icra2021_amd as altro
+    B, S, W = 8192, 20, 12
+    pb = altro.problems.gen_random_linear_batch(B, n=12, m=4, N=50, steps=5 + S * W + 200, seed=1)
+    mp, heat = altro.mpc.BatchMPC(pb), altro.mpc.BatchMPC(pb)
+    for m_ in (mp, heat):
+        m_.initial_solve()
+        for i in range(5): m_.step(i)
+    out = []
+    for w in range(W):
+        heat.run_async(100, first=5); heat.run_async(100, first=105); heat.synchronize()
+        altro.timing_reset(mp.solver)
+        mp.run_async(S, first=5 + w * S); mp.synchronize()
+        out.append(float(altro.timing_get(mp.solver).sum()))
+    print("%-12s" % sys.argv[1], " ".join("%6.2f" % x for x in out), " | mean %.2f ms" % (sum(out) / len(out)))
+else:
+    for tag, env in (("grouping", {}), ("no grouping", {"ALTRO_NO_GROUP": "1"}), ("grouping", {}), ("no grouping", {"ALTRO_NO_GROUP": "1"})):
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, __file__, tag], env=e)

@@ -7,12 +7,15 @@ if len(sys.argv) > 6:
     import altro_amd_loader
     import altro_mpc_icra2021_amd as altro
     n, m, N, B, S = map(int, sys.argv[1:6])
-    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S + 5, seed=10)
+    HEAT = 300   # MPC steps run right before the timed launch: the clocks of an idle GPU take tens of ms to come up
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S + 5 + HEAT, seed=10)
     mp = altro.mpc.BatchMPC(pb)
     mp.initial_solve()
     for i in range(5): mp.step(i)
+    for h in range(0, HEAT, 100): mp.run_async(100, first=5 + h)
+    mp.synchronize()
     altro.timing_reset(mp.solver)
-    mp.run_async(S, first=5); mp.synchronize()
+    mp.run_async(S, first=5 + HEAT); mp.synchronize()
     ms = altro.timing_get(mp.solver)
     nb = altro.work_counters(mp.solver)[0]; nfo = altro.reuse_counter(mp.solver); ngc = altro.confirm_counter(mp.solver)
     print("%-34s %.3f ms  %.2f M solves/s  passes/solve %.3f reuse %.3f confirm %.3f" % (sys.argv[6], ms.sum(), B * S / ms.sum() / 1e3, nb.sum() / (B * S), nfo.sum() / (B * S), ngc.sum() / (B * S)))
