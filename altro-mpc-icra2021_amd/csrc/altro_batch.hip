@@ -58,6 +58,7 @@ struct altro_handle {
   int mpc_shift = 1;
   int reuse = 1;  // gain reuse (solve_dpp16.h fosweep); ALTRO_NO_REUSE=1 at create time switches it off (tests)
   int lone = 1;  // backward_lone (solve_dpp16.h); ALTRO_NO_LONE=1 at create time switches it off (tests: lone == four-row pass bit for bit)
+  int group_max_steps = 32;  // fused launches of more steps are not grouped (ALTRO_GROUP_MAX_STEPS at create time: diagnostic)
   int shadow = 1;  // ALTRO_NO_SHADOW=1 at create time: rows that sit a phase out keep their own instance (solve_dpp16.h shadow_enter)
   int* cur = nullptr;
   int *perm = nullptr, *gscore = nullptr;  // [Bp] wave slot -> instance of a grouped MPC launch, and its sort key
@@ -456,7 +457,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   // (short launches only: over 100 steps nearly every window meets a bound at some point, the score stops separating the
   //  instances and clustering the pass-heavy rows -- they are also the ones with the hard solves -- lengthens the tail:
   //  measured 20 steps +2 %, 100 steps -3 %, tools/gpu_ab.py)
-  if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && nsteps <= 32 && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
+  if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && nsteps <= h->group_max_steps && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
     hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
                        first_step, nsteps, h->box_k0, h->box_k1, h->d.n + h->d.m);
     hipLaunchKernelGGL(k_group_rank, dim3(1), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp, h->group);
@@ -634,6 +635,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->device = device;
     { const char* nl = getenv("ALTRO_NO_LONE"); h->lone = (nl && nl[0] == '1') ? 0 : 1; }
     { const char* nsh = getenv("ALTRO_NO_SHADOW"); h->shadow = (nsh && nsh[0] == '1') ? 0 : 1; }
+    { const char* gms = getenv("ALTRO_GROUP_MAX_STEPS"); if (gms) h->group_max_steps = atoi(gms); }
     { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
     { const char* dw = getenv("ALTRO_DEBUG_TRACE_WAVE"); h->dbg_wave = dw ? atoi(dw) : -1; }
     { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
