@@ -34,7 +34,7 @@ struct altro_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   altro::LaunchRing ring;        // start/end event pairs of the most recent solve launches
-  double* Zsave = nullptr;       // [N][Bp][16]: Z0 of altro_batch_benchmark_solve
+  double* Zsave = nullptr;       // [Bp][N][16]: Z0 of altro_batch_benchmark_solve
   hipEvent_t bev0 = nullptr, bev1 = nullptr;
   long long *n_backward = nullptr, *n_rollout = nullptr, *wave_cycles = nullptr;
   long long *n_solves = nullptr, *n_iters = nullptr, *n_ok = nullptr, *n_trials = nullptr, *n_gconf = nullptr;
@@ -149,7 +149,7 @@ __global__ void k_pack_traj(const double* __restrict__ X, const double* __restri
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
   const int b = inst < B ? inst : B - 1;
-  double* dst = Zp + (use_cur ? (size_t)cur[inst] * plane : 0);
+  double* dst = Zp + (size_t)inst * (2 * (size_t)N + 1) * LW + (use_cur ? (size_t)cur[inst] * plane : 0);
   for (int k = 0; k < N; ++k) {
     double v = 0.0;
     bool wr = false;
@@ -161,7 +161,7 @@ __global__ void k_pack_traj(const double* __restrict__ X, const double* __restri
     } else {
       wr = true;
     }
-    if (wr) dst[((size_t)k * Bp + inst) * LW + j] = v;
+    if (wr) dst[(size_t)k * LW + j] = v;
   }
 }
 
@@ -170,9 +170,9 @@ __global__ void k_unpack_traj(double* __restrict__ X, double* __restrict__ U, co
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * LW) return;
   const int inst = t / LW, j = t % LW;
-  const double* src = Zp + (size_t)cur[inst] * plane;
+  const double* src = Zp + (size_t)inst * (2 * (size_t)N + 1) * LW + (size_t)cur[inst] * plane;
   for (int k = 0; k < N; ++k) {
-    const double v = src[((size_t)k * Bp + inst) * LW + j];
+    const double v = src[(size_t)k * LW + j];
     if (j < n) {
       if (X) X[((size_t)inst * N + k) * n + j] = v;
     } else if (j < n + m && k < N - 1) {
@@ -181,7 +181,7 @@ __global__ void k_unpack_traj(double* __restrict__ X, double* __restrict__ U, co
   }
 }
 
-// reference: Xref [B][Nt][n], Uref [B][Nt-1][m] -> Zref [Nt][Bp][16]
+// reference: Xref [B][Nt][n], Uref [B][Nt-1][m] -> Zref [Bp][Nt][16]
 __global__ void k_pack_ref(const double* __restrict__ X, const double* __restrict__ U, double* __restrict__ Zr,
                            int B, int Bp, int Nt, int n, int m) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +192,7 @@ __global__ void k_pack_ref(const double* __restrict__ X, const double* __restric
     double v = 0.0;
     if (j < n) v = X[((size_t)b * Nt + k) * n + j];
     else if (j < n + m && k < Nt - 1) v = U[((size_t)b * (Nt - 1) + k) * m + (j - n)];
-    Zr[((size_t)k * Bp + inst) * LW + j] = v;
+    Zr[((size_t)inst * Nt + k) * LW + j] = v;
   }
 }
 
@@ -240,9 +240,9 @@ __global__ void k_unpack_x0(double* __restrict__ x0, const double* __restrict__ 
   if (j < n) x0[(size_t)inst * n + j] = src[t];
 }
 
-// box duals: host [B][nk][2][nz] (dense, zero for unbounded elements)  <->  Lb [N+1][Bp][2][nbp]
+// box duals: host [B][nk][2][nz] (dense, zero for unbounded elements)  <->  Lb [Bp][N+1][2][nbp]
 __global__ void k_duals(double* __restrict__ host, double* __restrict__ Lb, const int* __restrict__ bslot, int nbp,
-                        int B, int Bp, int nz, int k0, int k1, int to_host) {
+                        int B, int Bp, int N, int nz, int k0, int k1, int to_host) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
@@ -253,8 +253,8 @@ __global__ void k_duals(double* __restrict__ host, double* __restrict__ Lb, cons
   for (int k = k0; k <= k1; ++k) {
     const size_t hi = (((size_t)b * nk + (k - k0)) * 2 + 0) * nz + j;
     const size_t lo = (((size_t)b * nk + (k - k0)) * 2 + 1) * nz + j;
-    const size_t dh = (((size_t)k * Bp + inst) * 2 + 0) * nbp + (sl >= 0 ? sl : 0);
-    const size_t dl = (((size_t)k * Bp + inst) * 2 + 1) * nbp + (sl >= 0 ? sl : 0);
+    const size_t dh = (((size_t)inst * (N + 1) + k) * 2 + 0) * nbp + (sl >= 0 ? sl : 0);
+    const size_t dl = (((size_t)inst * (N + 1) + k) * 2 + 1) * nbp + (sl >= 0 ? sl : 0);
     if (to_host) {
       if (inst < B) { host[hi] = sl >= 0 ? Lb[dh] : 0.0; host[lo] = sl >= 0 ? Lb[dl] : 0.0; }
     } else if (sl >= 0) {
@@ -272,31 +272,31 @@ __global__ void k_shift(double* __restrict__ Zp, const int* __restrict__ cur, si
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
   const int inst = t / LW, j = t % LW;
-  const size_t ks = (size_t)Bp * LW;
-  const size_t off = (size_t)inst * LW + j;
+  const size_t ks = LW;  // rows of an instance are consecutive (instance-major arrays)
   if (primal) {
-    double* z = Zp + (size_t)cur[inst] * plane + off;
+    double* z = Zp + (size_t)inst * (2 * (size_t)N + 1) * LW + (size_t)cur[inst] * plane + j;
     const int kend = (j < n) ? N - 1 : N - 2;  // x: knots 0..N-2 take k+1; u: knots 0..N-3
     if (j < n + m)
       for (int k = 0; k < kend; ++k) z[(size_t)k * ks] = z[(size_t)(k + 1) * ks];
   }
   if (dual && k1 >= k0) {  // the 16 threads of the instance share the 2*nbp elements of its compact rows
-    const size_t ls = (size_t)Bp * 2 * nbp;
+    const size_t ls = (size_t)2 * nbp;
     for (int e = j; e < 2 * nbp; e += LW) {
-      double* l = Lb + (size_t)inst * 2 * nbp + e;
+      double* l = Lb + (size_t)inst * (N + 1) * 2 * nbp + e;
       for (int k = k0; k < k1; ++k) l[(size_t)k * ls] = l[(size_t)(k + 1) * ls];
     }
   }
   if (dual && j < ncrows) {  // generic constraint rows on lane j: each constraint shifts inside its own range
+    double* lc = Lc + (size_t)inst * (N + 1) * LW + j;
     for (int k = 0; k < N - 1; ++k) {
       const int* cm = cmeta + ((size_t)k * LW + j) * 4;
-      if (cm[0] != 0 && k < cm[2]) Lc[(size_t)k * ks + off] = Lc[(size_t)(k + 1) * ks + off];
+      if (cm[0] != 0 && k < cm[2]) lc[(size_t)k * ks] = lc[(size_t)(k + 1) * ks];
     }
   }
 }
 
-// duals of one generic constraint block: host [B][nk][p]  <->  Lc [N+1][Bp][16], rows on lanes lane0..lane0+p-1
-__global__ void k_cduals(double* __restrict__ host, double* __restrict__ Lc, int B, int Bp, const int* __restrict__ lanes,
+// duals of one generic constraint block: host [B][nk][p]  <->  Lc [Bp][N+1][16], rows on lanes lane0..lane0+p-1
+__global__ void k_cduals(double* __restrict__ host, double* __restrict__ Lc, int B, int N, const int* __restrict__ lanes,
                          int p, int k0, int k1, int to_host) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * p) return;
@@ -304,7 +304,7 @@ __global__ void k_cduals(double* __restrict__ host, double* __restrict__ Lc, int
   const int nk = k1 - k0 + 1;
   for (int k = k0; k <= k1; ++k) {
     const size_t hi = ((size_t)inst * nk + (k - k0)) * p + r;
-    const size_t di = ((size_t)k * Bp + inst) * LW + lanes[r];
+    const size_t di = ((size_t)inst * (N + 1) + k) * LW + lanes[r];
     if (to_host) host[hi] = Lc[di];
     else Lc[di] = host[hi];
   }
@@ -315,12 +315,12 @@ __global__ void k_plane_copy(double* __restrict__ Zp, double* __restrict__ Zs, c
                              int Bp, int N, int save) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Bp * LW) return;
-  const int inst = t / LW;
-  double* z = Zp + (size_t)cur[inst] * plane;
-  const size_t ks = (size_t)Bp * LW;
+  const int inst = t / LW, j = t % LW;
+  double* z = Zp + (size_t)inst * (2 * (size_t)N + 1) * LW + (size_t)cur[inst] * plane + j;
+  double* zs = Zs + (size_t)inst * N * LW + j;
   for (int k = 0; k < N; ++k) {
-    if (save) Zs[(size_t)k * ks + t] = z[(size_t)k * ks + t];
-    else z[(size_t)k * ks + t] = Zs[(size_t)k * ks + t];
+    if (save) zs[(size_t)k * LW] = z[(size_t)k * LW];
+    else z[(size_t)k * LW] = zs[(size_t)k * LW];
   }
 }
 
@@ -334,7 +334,7 @@ __global__ void k_plane_copy(double* __restrict__ Zp, double* __restrict__ Zs, c
 // wave (tests: instance results do not depend on the batch; lone-row == four-row pass bit for bit).
 // one 16-lane row per instance (lane j = element j of z: coalesced 128-byte reads), 16 instances per block
 __global__ void k_group_score(const double* __restrict__ Zref, const double* __restrict__ zmin, const double* __restrict__ zmax,
-                              int* __restrict__ score, int Bp, int first, int nsteps, int k0, int k1, int nz) {
+                              int* __restrict__ score, int Bp, int Nt, int first, int nsteps, int k0, int k1, int nz) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = t / LW, j = t % LW;
   const bool live = b < Bp;
@@ -349,7 +349,7 @@ __global__ void k_group_score(const double* __restrict__ Zref, const double* __r
   unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
   const int sh = (threadIdx.x & 63) & ~15;   // this row's 16 bits of the wave's ballot
   for (int a = 0; a < na; ++a) {
-    const double z = Zref[((size_t)(a0 + a) * Bp + bb) * LW + j];
+    const double z = Zref[((size_t)bb * Nt + (a0 + a)) * LW + j];
     const bool act = (fh && z >= hi - m) || (fl && z <= lo + m);
     const bool any = ((__ballot(act) >> sh) & 0xFFFFull) != 0ull;
     if (any) bits[a >> 6] |= 1ull << (a & 63);
@@ -404,13 +404,27 @@ __global__ void __launch_bounds__(256) k_group_rank(const int* __restrict__ scor
     const int rank = off[sc]++;
     int slot = rank;                                  // mode 1: sorted, the instances with the fewest expected passes first
     if (mode == 2) {                                  // sorted waves, light and heavy ones alternating in the block order
-      const int wr = rank / 4, q = rank % 4;
-      slot = ((wr < W / 2) ? 2 * wr : 2 * (W - 1 - wr) + 1) * 4 + q;
+      const int wr = rank / 4, q = rank % 4;          // (a permutation for odd W too: the lighter (W + 1) / 2 take the even slots)
+      slot = ((wr < (W + 1) / 2) ? 2 * wr : 2 * (W - 1 - wr) + 1) * 4 + q;
     } else if (mode == 3) {                           // every wave gets one instance of each quartile
       slot = (rank % W) * 4 + rank / W;
+    } else if (mode == 4) {                           // sorted waves, the upper half in DESCENDING order: with W = 2 waves per
+      const int wr = rank / 4, q = rank % 4;          // SIMD the dispatcher puts blocks i and i + W / 2 on one SIMD, so the
+      const int hw = (W + 1) / 2;                     // wave with the most expected passes shares its SIMD with the one
+      slot = ((wr < hw) ? wr : hw + (W - 1 - wr)) * 4 + q;   // with the fewest (min-max pairing), not with a middle one
     }
     perm[slot] = i;
   }
+}
+
+// initial_trajectory!(prob, Z): plane 0 of Z <- the first N knots of the track (mpc.jl:19-20,45)
+__global__ void k_window_copy(double* __restrict__ Zp, const double* __restrict__ Zr, int Bp, int N, int Nt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Bp * LW) return;
+  const int inst = t / LW, j = t % LW;
+  double* z = Zp + (size_t)inst * (2 * (size_t)N + 1) * LW + j;
+  const double* r = Zr + (size_t)inst * Nt * LW + j;
+  for (int k = 0; k < N; ++k) z[(size_t)k * LW] = r[(size_t)k * LW];
 }
 
 __global__ void k_fill(double* p, double v, size_t nelem) {
@@ -428,7 +442,7 @@ static bool supported_dims(int n, int m) {
 static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare_only = 0) {
   altro::SolveParams p{};
   p.prepare_only = prepare_only;
-  p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N;
+  p.B = h->d.batch; p.Bp = h->Bp; p.N = h->d.N; p.Nt = h->Nt;
   p.kref = h->kref;
   p.first_step = first_step; p.nsteps = nsteps;
   p.noise = h->noise; p.noise_w = h->noise_w; p.noise_grp = h->noise_grp; p.noise_mode = h->noise_mode; p.mpc_shift = h->mpc_shift;
@@ -458,7 +472,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   //  instances and clustering the pass-heavy rows -- they are also the ones with the hard solves -- lengthens the tail:
   //  measured 20 steps +2 %, 100 steps -3 %, tools/gpu_ab.py)
   if (h->group && h->reuse && !h->o.strict && nsteps >= 4 && nsteps <= h->group_max_steps && !prepare_only && h->ncrows == 0 && h->box_k1 >= h->box_k0 && h->Bp <= 32768) {
-    hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp,
+    hipLaunchKernelGGL(k_group_score, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Zref, h->zmin, h->zmax, h->gscore, h->Bp, h->Nt,
                        first_step, nsteps, h->box_k0, h->box_k1, h->d.n + h->d.m);
     hipLaunchKernelGGL(k_group_rank, dim3(1), dim3(256), 0, h->stream, h->gscore, h->perm, h->Bp, h->group);
     p.perm = h->perm;
@@ -640,7 +654,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     { const char* dw = getenv("ALTRO_DEBUG_TRACE_WAVE"); h->dbg_wave = dw ? atoi(dw) : -1; }
     { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
     { const char* ng = getenv("ALTRO_NO_GROUP"); h->group = (ng && ng[0] == '1') ? 0 : 1; }
-    { const char* gm = getenv("ALTRO_GROUP_MODE"); if (gm && gm[0] >= '0' && gm[0] <= '3') h->group = gm[0] - '0'; }
+    { const char* gm = getenv("ALTRO_GROUP_MODE"); if (gm && gm[0] >= '0' && gm[0] <= '4') h->group = gm[0] - '0'; }
     { const char* nr = getenv("ALTRO_NO_REUSE"); h->reuse = (nr && nr[0] == '1') ? 0 : 1; }
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {
@@ -1184,7 +1198,7 @@ int32_t altro_batch_set_initial_trajectory(altro_handle* h, const double* X, con
     if (rc) return rc;
     if (X && (rc = upload(h, X, cx, 0))) return rc;
     if ((rc = upload(h, U, cu, cx))) return rc;
-    const size_t plane = N * (size_t)h->Bp * LW;
+    const size_t plane = N * (size_t)LW;   // offset of plane 1 inside an instance's block of Z
     hipLaunchKernelGGL(k_pack_traj, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->stage + cx, h->Z,
                        h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m, 1, X ? 1 : 0);
     HIPCHK(h, hipGetLastError());
@@ -1198,7 +1212,7 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
     WIDE_FWD(h, shift_fill(primal, dual));
     if (!h) return ALTRO_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t plane = (size_t)h->d.N * h->Bp * LW;
+    const size_t plane = (size_t)h->d.N * LW;
     hipLaunchKernelGGL(k_shift, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->cur, plane, h->Lb,
                        h->nbp, h->Bp, h->d.N, h->d.n, h->d.m, h->box_k0, h->box_k1, primal ? 1 : 0, dual ? 1 : 0, h->Lc,
                        h->cmeta, h->ncrows);
@@ -1243,7 +1257,7 @@ static int launch_polish(altro_handle* h) {
     h->pn_bm = bm;
   }
   altro_pn::PnParams q{};
-  q.B = h->d.batch; q.Bp = h->Bp; q.N = h->d.N; q.n = h->d.n; q.m = h->d.m; q.bm = bm;
+  q.B = h->d.batch; q.Bp = h->Bp; q.N = h->d.N; q.Nt = h->Nt; q.n = h->d.n; q.m = h->d.m; q.bm = bm;
   q.box_k0 = h->box_k0; q.box_k1 = h->box_k1; q.ncrows = h->ncrows;
   q.con_istride = h->con_per_instance ? (unsigned)(h->d.N * LW * LW) : 0u;
   q.Grow = h->Grow; q.fvec = h->fvec; q.wd = h->wd; q.wf = h->wf; q.zmin = h->zmin; q.zmax = h->zmax; q.x0 = h->x0;
@@ -1315,7 +1329,7 @@ static int get_traj(altro_handle* h, double* X, double* U) {
   const size_t cx = B * N * n, cu = B * (N - 1) * m;
   int rc = ensure_stage(h, (cx + cu) * sizeof(double));
   if (rc) return rc;
-  const size_t plane = N * (size_t)h->Bp * LW;
+  const size_t plane = N * (size_t)LW;
   hipLaunchKernelGGL(k_unpack_traj, grid_for(B * LW), dim3(256), 0, h->stream, X ? h->stage : nullptr,
                      U ? h->stage + cx : nullptr, h->Z, h->cur, plane, (int)B, h->Bp, (int)N, (int)n, (int)m);
   HIPCHK(h, hipGetLastError());
@@ -1352,7 +1366,7 @@ static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_ho
     if (!to_host && (rc = upload(h, lambda, cnt))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->lanebuf, cb.lanes, LW * sizeof(int), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_cduals, grid_for((size_t)h->d.batch * cb.p), dim3(256), 0, h->stream, h->stage, h->Lc,
-                       h->d.batch, h->Bp, h->lanebuf, cb.p, cb.k0, cb.k1, to_host);
+                       h->d.batch, h->d.N, h->lanebuf, cb.p, cb.k0, cb.k1, to_host);
     HIPCHK(h, hipGetLastError());
     if (to_host) HIPCHK(h, hipMemcpyAsync(lambda, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1366,7 +1380,7 @@ static int duals_xfer(altro_handle* h, int32_t con_id, double* lambda, int to_ho
   if (rc) return rc;
   if (!to_host && (rc = upload(h, lambda, cnt))) return rc;
   hipLaunchKernelGGL(k_duals, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->stage, h->Lb, h->bslot, h->nbp,
-                     h->d.batch, h->Bp, nz, h->box_k0, h->box_k1, to_host);
+                     h->d.batch, h->Bp, h->d.N, nz, h->box_k0, h->box_k1, to_host);
   HIPCHK(h, hipGetLastError());
   if (to_host) HIPCHK(h, hipMemcpyAsync(lambda, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1426,22 +1440,22 @@ int32_t altro_batch_get_gains(altro_handle* h, double* K, double* d) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t n = h->d.n, m = h->d.m, N = h->d.N, B = h->d.batch, Bp = h->Bp;
-    std::vector<double> kd((N - 1) * Bp * m * LW);
+    std::vector<double> kd(N * Bp * m * LW);
     HIPCHK(h, hipMemcpy(kd.data(), h->KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost));
     // an iteration confirmed by the costate sweep ran no backward pass: K is the previous pass's (the same
     // matrix: the active set was verified unchanged), its feedforward terms are zero (include/altro_batch.h, strict)
     std::vector<int> dz(Bp);
     HIPCHK(h, hipMemcpy(dz.data(), h->dzero, Bp * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<double> df((N - 1) * Bp * LW);
+    std::vector<double> df((N + 1) * Bp * LW);
     HIPCHK(h, hipMemcpy(df.data(), h->Dff, df.size() * sizeof(double), hipMemcpyDeviceToHost));
-    // device layout KD [k][instance][control a][lane]: state lane j holds K[a][j] (the control lanes carry the factors of
-    // Quu); Dff [k][instance][lane]: control lane n+a holds d[a]
+    // device layout KD [instance][k][control a][lane]: state lane j holds K[a][j] (the control lanes carry the factors of
+    // Quu); Dff [instance][k (N + 1 rows)][lane]: control lane n+a holds d[a]
     for (size_t b = 0; b < B; ++b)
       for (size_t k = 0; k + 1 < N; ++k)
         for (size_t a = 0; a < m; ++a) {
-          const double* row = kd.data() + ((k * Bp + b) * m + a) * LW;
+          const double* row = kd.data() + ((b * N + k) * m + a) * LW;
           if (K) for (size_t j = 0; j < n; ++j) K[((b * (N - 1) + k) * n + j) * m + a] = row[j];
-          if (d) d[(b * (N - 1) + k) * m + a] = dz[b] ? 0.0 : df[(k * Bp + b) * LW + n + a];
+          if (d) d[(b * (N - 1) + k) * m + a] = dz[b] ? 0.0 : df[(b * (N + 1) + k) * LW + n + a];
         }
     return ALTRO_OK;
   });
@@ -1600,11 +1614,10 @@ int32_t altro_mpc_set_track(altro_handle* h, const double* Xtrack, const double*
     int rc = set_ref_common(h, Xtrack, Utrack, Nt);
     if (rc) return rc;
     // initial_trajectory!(prob, Z): the first window of the track (mpc.jl:19-20,45)
-    const size_t row = (size_t)h->Bp * LW;
     HIPCHK(h, hipMemsetAsync(h->cur, 0, h->Bp * sizeof(int), h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->Z, h->Zref, (size_t)h->d.N * row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->x0, h->Zref, row * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    // x0 lanes >= n must be zero: u lanes of Zref knot 0 hold u_0, clear them through the pack path
+    hipLaunchKernelGGL(k_window_copy, grid_for((size_t)h->Bp * LW), dim3(256), 0, h->stream, h->Z, h->Zref, h->Bp, h->d.N, Nt);
+    HIPCHK(h, hipGetLastError());
+    // x0 <- the track's first state, through the pack path (its lanes >= n must be zero)
     {
       const size_t cnt = (size_t)h->d.batch * h->d.n;
       std::vector<double> x0(cnt);
@@ -1712,8 +1725,8 @@ int32_t altro_batch_benchmark_solve(altro_handle* h, int32_t samples, int32_t ev
     if (!h) return ALTRO_ERR_INVALID_ARG;
     if (samples < 1 || evals < 1) FAIL(h, ALTRO_ERR_INVALID_ARG, "samples and evals must be positive");
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t plane = (size_t)h->d.N * h->Bp * LW;
-    if (!h->Zsave) HIPCHK(h, hipMalloc(&h->Zsave, plane * sizeof(double)));
+    const size_t plane = (size_t)h->d.N * LW;
+    if (!h->Zsave) HIPCHK(h, hipMalloc(&h->Zsave, plane * h->Bp * sizeof(double)));
     const dim3 grid = grid_for((size_t)h->Bp * LW);
     // Z0 = deepcopy(get_trajectory(solver))
     hipLaunchKernelGGL(k_plane_copy, grid, dim3(256), 0, h->stream, h->Z, h->Zsave, h->cur, plane, h->Bp, h->d.N, 1);

@@ -28,12 +28,13 @@ constexpr int BMAX = 56;  // rows a block may hold (2 n + active box sides + gen
 
 struct PnParams {
   int B, Bp, N, n, m, bm;
+  int Nt;                 // rows per instance of Zref
   int box_k0, box_k1, ncrows;
   unsigned con_istride;   // as SolveParams
   const double *Grow, *fvec, *wd, *wf, *zmin, *zmax, *x0;
   const double *Acon, *bcon;
   const int* cmeta;
-  double* Z;              // [2][N][Bp][16] (+ trash row): plane cur is polished, plane cur^1 is the trial buffer
+  double* Z;              // [Bp][2 N + 1][16] (two planes of N rows + trash row per instance): plane cur is polished, plane cur^1 is the trial buffer
   const double* Zref;     // window start kref
   int kref;
   int* cur;
@@ -81,10 +82,10 @@ struct Pn {
   }
 
   __device__ __forceinline__ const double* zrow(int plane, int k) const {
-    return P.Z + ((size_t)plane * N + k) * (size_t)P.Bp * LW + (size_t)inst * LW;
+    return P.Z + ((size_t)inst * (2 * (size_t)N + 1) + (size_t)plane * N + k) * LW;
   }
   __device__ __forceinline__ double* zrow_w(int plane, int k) const {
-    return P.Z + ((size_t)plane * N + k) * (size_t)P.Bp * LW + (size_t)inst * LW;
+    return P.Z + ((size_t)inst * (2 * (size_t)N + 1) + (size_t)plane * N + k) * LW;
   }
   __device__ __forceinline__ double hinv(int k, int j) const {
     const double h = (k < N - 1) ? P.wd[j] : (j < n ? P.wf[j] : 0.0);
@@ -435,7 +436,7 @@ struct Pn {
     double J = 0.0, cm = 0.0;
     for (int k = tid; k < N; k += 64) {
       const double* zr = zrow(cur, k);
-      const double* rr = P.Zref + ((size_t)(P.kref + k) * P.Bp + inst) * LW;
+      const double* rr = P.Zref + ((size_t)inst * P.Nt + (size_t)(P.kref + k)) * LW;
       const int lim = (k == N - 1) ? n : nz;
       for (int j = 0; j < lim; ++j) {
         const double e = zr[j] - rr[j];

@@ -96,6 +96,7 @@ __device__ __forceinline__ bool operator!=(const AHash& x, const AHash& y) { ret
 
 struct SolveParams {
   int B, Bp, N;
+  int Nt;                // knots held by Zref (rows per instance)
   int kref;              // first knot of the reference window inside Zref (plain solve)
   int box_k0, box_k1;    // knot range of the BOX constraint (box_k1 < box_k0: none)
   int first_step;        // MPC mode: first step index
@@ -109,17 +110,17 @@ struct SolveParams {
   const double* zmin;    // [16]
   const double* zmax;    // [16]
   double* x0;            // [Bp][16]
-  const double* Zref;    // [Nt][Bp][16]
+  const double* Zref;    // [Bp][Nt][16]
   const double* noise;   // [steps][B][n] unit normals of the plant noise (may be null)
   const double* noise_w; // [16] per-state noise weight
   const int* noise_grp;  // [16] per-state norm group (0 or 1)
   int noise_mode;        // 0: w_i * ||x||_inf (random_linear_problem.jl:129); 1: w_i * ||x[group_i]||_2
                          // (simple_rocket.jl:65-71); 2: w_i (absolute, flexible_sat_mpc.jl:266)
   int mpc_shift;         // 1: shift_fill primal + dual at every MPC step (default); 0: keep (flexible_sat_mpc.jl:275-276)
-  double* Z;             // [2][N][Bp][16]  ping-pong trajectories, + one trash row [Bp][16] at the end
+  double* Z;             // [Bp][2 N + 1][16]  per instance: two ping-pong planes of N rows, then one trash row
   int* cur;              // [Bp] which plane of Z is current
   const int* perm;       // [Bp] wave slot -> instance (grouped MPC launches: altro_batch.hip k_group_score); null: identity
-  double* Lb;            // [N+1][Bp][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
+  double* Lb;            // [Bp][N+1][2][nbp] box duals of the nbp bounded elements of z: side 0 = duals of
                          // z - zmax <= 0, side 1 = duals of zmin - z <= 0  (knot N = trash row)
   const int* bslot;      // [16] slot of lane j's element among the bounded ones, -1 if unbounded
   int nbp;               // slots per side (>= 1)
@@ -143,13 +144,13 @@ struct SolveParams {
   const int* ckn;        // [16] canonical knot of each constraint lane
   int con_inv;           // 1: the row a lane holds is the same at every knot of its range (time-invariant tables): the
                          // streaming sweeps load it once, from knot ckn[lane]
-  double* Lc;            // [N+1][Bp][16] duals of the constraint rows (knot N = trash row)
+  double* Lc;            // [Bp][N+1][16] duals of the constraint rows (knot N = trash row)
   int ncrows;            // 0: no generic constraints
-  double* Qz;            // [N+1][Bp][16] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced
+  double* Qz;            // [Bp][N+1][16] gradient of the AL cost at the trajectory the last alpha = 1 rollout produced
                          // (l_x on the state lanes, l_u on the control lanes; knot N = trash): input of the costate sweep
-  double* KD;            // [N][Bp][NU][16] gains: row a = K[a][0..NX-1] in the x lanes; lane NX + b (b <= a) holds entry (a, b) of
+  double* KD;            // [Bp][N][NU][16] gains: row a = K[a][0..NX-1] in the x lanes; lane NX + b (b <= a) holds entry (a, b) of
                          // the factors of Quu = L D L' (1 / D_a on the diagonal, L below it); block N-1 = trash
-  double* Dff;           // [N+1][Bp][16] feedforward terms: d[a] on lane NX + a (knot N = trash)
+  double* Dff;           // [Bp][N+1][16] feedforward terms: d[a] on lane NX + a (knot N = trash)
   AHash* ahash;          // [Bp][16] per lane: active set of the backward pass that left the gains in KD (kept between launches)
   double* kmu;           // [Bp] penalty of that pass; < 0: the gains in KD must not be reused
   long long* n_fo;       // [Bp] iterations that took their gains from memory (first-order sweep instead of a backward pass)
@@ -404,11 +405,11 @@ struct Solver {
   int lane, j, inst;
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
-  unsigned kstride;  // Bp*16                 that every array stays below 2^32 bytes)
+                     //                       that every array stays below 2^32 bytes)
   unsigned lslot;    // this lane's slot in the compact dual rows (0 for unbounded lanes: dummy)
   bool bounded;
   ALTRO_STAMP(long long t_bw; long long t_rc; long long t_ro; long long t_td; long long t_du; long long t_ls; long long t_fo; long long t_aj; long long t_bl;
-              long long c_bw; long long c_fo; long long c_aj; long long c_rc; long long c_ls;)
+              long long c_bw; long long c_fo; long long c_aj; long long c_rc; long long c_ls; long long t_start;)
 
   struct LaneConst {
     double wd, wf, zmin, zmax;
@@ -427,7 +428,6 @@ struct Solver {
     is_x = j < NX;
     is_u = (j >= NX) && (j < NZ);
     rowoff = (unsigned)inst * LW + j;
-    kstride = (unsigned)P.Bp * LW;
     {
       const int sl = P.bslot[j];
       bounded = sl >= 0;
@@ -492,18 +492,37 @@ struct Solver {
   // start of a phase keeps those computations (a handful of integer instructions) inside the phase.
   __device__ __forceinline__ void phase_begin() { asm volatile("" : "+v"(j), "+v"(rowoff), "+v"(lslot), "+v"(inst)); }
 
-  __device__ __forceinline__ unsigned at(int k) const { return (unsigned)k * kstride + rowoff; }
-  // plane c of Z as an element offset (per instance: cur differs between rows)
-  __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * kstride; }
-  __device__ __forceinline__ unsigned trash_z() const { return 2u * (unsigned)P.N * kstride + rowoff; }
-  // compact dual rows: element offset of (knot k, side, this lane's slot); knot N is the trash row
+  // "these loads have landed": an empty asm that reads the registers, so that hipcc waits for them HERE (see backward())
+  static __device__ __forceinline__ void landed_in(double& a) { asm volatile("" : "+v"(a)); }
+  template <int M, int I = 0>
+  static __device__ __forceinline__ void landed(double (&a)[M]) {
+    if constexpr (I < M) {
+      asm volatile("" : "+v"(a[I]));
+      landed<M, I + 1>(a);
+    }
+  }
+
+  // INSTANCE-MAJOR arrays (DESIGN.md "Data layout"): everything an instance owns in one array is contiguous, row after
+  // row of 16 lanes, so a sweep over the knots walks one 128-byte line after the other (one DRAM page, one TLB entry per
+  // array) and a row index becomes an address with a shift -- with the knots outermost every knot of every array sat in
+  // its own megabyte and a per-lane row index cost a quarter-rate v_mul_lo_u32.
+  //   Z    [Bp][2 N + 1][16]  rows 0..N-1 plane 0, N..2N-1 plane 1, row 2 N the trash row
+  //   Zref [Bp][Nt][16]
+  //   Lc, Qz, Dff [Bp][N + 1][16]  (row N = trash)
+  __device__ __forceinline__ unsigned zat(int r) const { return ((unsigned)inst * (2u * (unsigned)P.N + 1u) + (unsigned)r) * LW + j; }
+  __device__ __forceinline__ unsigned rat(int k) const { return ((unsigned)inst * (unsigned)P.Nt + (unsigned)k) * LW + j; }
+  __device__ __forceinline__ unsigned qat(int k) const { return ((unsigned)inst * ((unsigned)P.N + 1u) + (unsigned)k) * LW + j; }
+  // plane c of Z as an element offset inside the instance's block (per instance: cur differs between rows)
+  __device__ __forceinline__ unsigned plane(int c) const { return (unsigned)c * (unsigned)P.N * LW; }
+  __device__ __forceinline__ unsigned trash_z() const { return zat(2 * P.N); }
+  // compact dual rows Lb [Bp][N + 1][2][nbp]: element offset of (knot k, side, this lane's slot); knot N is the trash row
   __device__ __forceinline__ unsigned lb_at(int k, int side) const {
-    return (((unsigned)k * P.Bp + inst) * 2u + (unsigned)side) * (unsigned)P.nbp + lslot;
+    return (((unsigned)inst * ((unsigned)P.N + 1u) + (unsigned)k) * 2u + (unsigned)side) * (unsigned)P.nbp + lslot;
   }
   __device__ __forceinline__ unsigned trash_l(int side) const { return lb_at(P.N, side); }
   __device__ __forceinline__ bool box_at(int k) const { return k >= P.box_k0 && k <= P.box_k1; }
-  __device__ __forceinline__ unsigned kd_at(int k, int row) const {
-    return (((unsigned)k * P.Bp + inst) * NU + row) * LW + j;
+  __device__ __forceinline__ unsigned kd_at(int k, int row) const {  // KD [Bp][N][NU][16]
+    return (((unsigned)inst * (unsigned)P.N + (unsigned)k) * NU + row) * LW + j;
   }
   static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
   static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -607,7 +626,7 @@ struct Solver {
     const double mu = rs->mu;
     const int cur = rs->cur, kref = rs->kref;
     const unsigned zs = plane(cur);
-    const unsigned zd = OPEN ? (take ? plane(cur) : trash_z() - 0u) : plane(cur ^ 1);
+    const unsigned zd = plane(OPEN ? cur : cur ^ 1);  // (closed loop: the plane the trial is written to)
     // Stores of rows that sit a phase out go to trash rows.  The select is made on the KNOT INDEX (one
     // v_cndmask); selecting between two computed addresses made hipcc emit divergent branches with
     // scratch reloads and s_waitcnt vmcnt(0) inside the loop, which serialises the prefetch ring.
@@ -654,8 +673,8 @@ struct Solver {
     auto load = [&](int k, KnotIn& in, ConK& ck) {
       const int ku = imin(k + 1, N - 2);
       const int kl = imax(imin(k + 1, k1), 0);
-      in.z = ldg(P.Z, zs + at(shu ? ku : k));
-      in.zr = ldg(P.Zref, at(kref + k));
+      in.z = ldg(P.Z, zs + zat(shu ? ku : k));
+      in.zr = ldg(P.Zref, rat(kref + k));
       const int kk = shl ? kl : k;
       in.lhi = ldg(P.Lb, lb_at(kk, 0));
       in.llo = ldg(P.Lb, lb_at(kk, 1));
@@ -665,7 +684,7 @@ struct Solver {
         } else {
           sfor<0, NU>([&](auto c) { in.kcol[decltype(c)::value] = ldg(P.KD, kd_at(k, decltype(c)::value)); });
         }
-        in.dff = ldg(P.Dff, at(k));
+        in.dff = ldg(P.Dff, qat(k));
       }
       in.lc = 0.0;
       in.lcn = 0.0;
@@ -674,8 +693,8 @@ struct Solver {
         // the shifted read (knot k + 1 while that is inside the row's own range) is chosen in `stage`:
         // an address that depends on the row's metadata would make this a dependent load, and the
         // in-order vmcnt wait in front of it drains the whole prefetch ring
-        in.lc = ldg(P.Lc, at(k));
-        if constexpr (OPEN) in.lcn = ldg(P.Lc, at(imin(k + 1, N - 1)));
+        in.lc = ldg(P.Lc, qat(k));
+        if constexpr (OPEN) in.lcn = ldg(P.Lc, qat(imin(k + 1, N - 1)));
       }
     };
 
@@ -687,7 +706,7 @@ struct Solver {
       double zb;
       if constexpr (OPEN) {
         zb = is_x ? xb : in.z;
-        stg(P.Z, at(take ? cur * N + k : 2 * N), zb);
+        stg(P.Z, zat(take ? cur * N + k : 2 * N), zb);
         const int kl_ = wl ? k : P.N;  // knot N of Lb is the trash row
         stg(P.Lb, lb_at(kl_, 0), lhi);
         stg(P.Lb, lb_at(kl_, 1), llo);
@@ -734,14 +753,14 @@ struct Solver {
         zb = is_x ? xb : ub;
         changed = changed | ((is_x | is_u) & (zb != in.z));
         big = big | ((is_x | is_u) & !(fabs(zb - in.z) <= 1e-7 * (1.0 + fabs(in.z))));
-        stg(P.Z, zd + at(k), zb);
+        stg(P.Z, zd + zat(k), zb);
       }
       if constexpr (!CONES) {
         double qz;
         unsigned code;
         Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, OPEN ? lhi : in.lhi, OPEN ? llo : in.llo, bx, viol, qz, code);
         qh = hash_add(qh, code, k);
-        stg(P.Qz, at(storeq ? k : N), qz);
+        stg(P.Qz, qat(storeq ? k : N), qz);
       } else {
         Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
       }
@@ -753,7 +772,7 @@ struct Solver {
         const ConeEval e = cone_eval<false>(v, act ? lck : 0.0, mu, ck.cm, act, dmax, so2);
         Jacc += e.cost;
         viol = fmax(viol, e.viol);
-        if constexpr (OPEN) stg(P.Lc, at((wr_l & act) ? k : P.N), lck);
+        if constexpr (OPEN) stg(P.Lc, qat((wr_l & act) ? k : P.N), lck);
       }
       limit = limit | ((is_x | is_u) & !(fabs(zb) <= lim));
       double acc4[4] = {fv, 0.0, 0.0, 0.0};
@@ -763,13 +782,13 @@ struct Solver {
 
     // terminal-knot operands (independent of the pipeline)
     const int kt = N - 1;
-    const double t_zr = ldg(P.Zref, at(kref + kt));
+    const double t_zr = ldg(P.Zref, rat(kref + kt));
     const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
     double t_z = 0.0, t_lc = 0.0;
     ConK t_ck;
-    if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
+    if constexpr (!OPEN) t_z = ldg(P.Z, zs + zat(kt));
     if constexpr (CONES) {
-      t_lc = ldg(P.Lc, at(kt));
+      t_lc = ldg(P.Lc, qat(kt));
       con_load(kt, t_ck);
     }
 
@@ -781,6 +800,17 @@ struct Solver {
     sfor<0, PD>([&](auto u) {
       constexpr int U = decltype(u)::value;
       load(imin(U, N - 2), ring[U], cring[U]);
+    });
+    // The first fill of the ring is waited for here, once (see backward(): with these loads pending on the way into the
+    // loop, hipcc's merged wait-count state asked every body for `vmcnt(PD * loads - 1)` at its first use -- right for the
+    // first trip, half the ring's lead time on every later one, where the stores of the previous body are in flight too).
+    sfor<0, PD>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      asm volatile("" : "+v"(ring[U].z), "+v"(ring[U].zr), "+v"(ring[U].lhi), "+v"(ring[U].llo));
+      if constexpr (!OPEN) {
+        landed(ring[U].kcol);
+        asm volatile("" : "+v"(ring[U].dff));
+      }
     });
     const int ngroups = (N - 1) / PD;
     int k = 0;
@@ -801,14 +831,14 @@ struct Solver {
     {  // terminal knot: state only
       const bool bx = box_at(kt);
       const double zb = is_x ? xb : 0.0;
-      if constexpr (OPEN) stg(P.Z, at(take ? cur * N + kt : 2 * N), zb);
-      else stg(P.Z, zd + at(kt), zb);
+      if constexpr (OPEN) stg(P.Z, zat(take ? cur * N + kt : 2 * N), zb);
+      else stg(P.Z, zd + zat(kt), zb);
       if constexpr (!CONES) {
         double qz;
         unsigned code;
         Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
         qh = hash_add(qh, code, kt);
-        stg(P.Qz, at(storeq ? kt : N), is_x ? qz : 0.0);
+        stg(P.Qz, qat(storeq ? kt : N), is_x ? qz : 0.0);
       } else {
         Jcls[0] += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
       }
@@ -894,20 +924,20 @@ struct Solver {
       sfor<0, 4>([&](auto u) {
         constexpr int U = decltype(u)::value;
         const int ku = imin(k0 + U, N - 2);
-        r.z[U] = ldg(P.Z, zs + at(shu ? imin(ku + 1, N - 2) : ku));
+        r.z[U] = ldg(P.Z, zs + zat(shu ? imin(ku + 1, N - 2) : ku));
         if constexpr (!OPEN) {
           if constexpr (NU <= 4) {
             sfor<0, 4>([&](auto c) { r.kcol[U][decltype(c)::value] = ldg(P.KD, kd_at(ku, 0) + kofs[decltype(c)::value]); });
           } else {
             sfor<0, NU>([&](auto c) { r.kcol[U][decltype(c)::value] = ldg(P.KD, kd_at(ku, decltype(c)::value)); });
           }
-          r.dff[U] = ldg(P.Dff, at(ku));
+          r.dff[U] = ldg(P.Dff, qat(ku));
         }
       });
     };
     auto load_cst = [&](int k0, Cst& c) {
       const int kq = imin(k0 + rr, N - 2);
-      c.zr = ldg(P.Zref, at(kref + kq));
+      c.zr = ldg(P.Zref, rat(kref + kq));
       const int kk = shift ? imax(imin(kq + 1, k1), 0) : kq;
       c.lhi = ldg(P.Lb, lb_at(kk, 0));
       c.llo = ldg(P.Lb, lb_at(kk, 1));
@@ -973,12 +1003,12 @@ struct Solver {
       const bool bx = box_at(kq) & valid;
       const double lhi = bx ? c.lhi : 0.0, llo = bx ? c.llo : 0.0;
       if constexpr (OPEN) {
-        stg(P.Z, at(valid ? cur * N + kq : 2 * N), zm);
+        stg(P.Z, zat(valid ? cur * N + kq : 2 * N), zm);
         const int kl_ = (wl & valid) ? kq : P.N;  // knot N of Lb is the trash row
         stg(P.Lb, lb_at(kl_, 0), lhi);
         stg(P.Lb, lb_at(kl_, 1), llo);
       } else {
-        stg(P.Z, valid ? zd + at(kq) : trash_z(), zm);
+        stg(P.Z, zat(valid ? (cur ^ 1) * N + kq : 2 * N), zm);  // (a select of the knot index, not of two addresses: see rollout())
         changed = changed | (valid & (is_x | is_u) & (zm != zo));
         big = big | (valid & (is_x | is_u) & !(fabs(zm - zo) <= 1e-7 * (1.0 + fabs(zo))));
       }
@@ -987,16 +1017,16 @@ struct Solver {
       // an invalid knot (past the last stage knot) contributes exact zeros: weight 0, box off
       Jc += lane_cost_grad<true>(lc, mu, zm, c.zr, valid ? lc.wd : 0.0, lhi, llo, bx, viol, qz, code);
       qh = hash_add(qh, code, kq);
-      stg(P.Qz, at(valid ? kq : N), qz);
+      stg(P.Qz, qat(valid ? kq : N), qz);
       limit = limit | (valid & (is_x | is_u) & !(fabs(zm) <= lim));
     };
 
     // terminal-knot operands (independent of the pipeline)
     const int kt = N - 1;
-    const double t_zr = ldg(P.Zref, at(kref + kt));
+    const double t_zr = ldg(P.Zref, rat(kref + kt));
     const double t_lhi = ldg(P.Lb, lb_at(kt, 0)), t_llo = ldg(P.Lb, lb_at(kt, 1));
     double t_z = 0.0;
-    if constexpr (!OPEN) t_z = ldg(P.Z, zs + at(kt));
+    if constexpr (!OPEN) t_z = ldg(P.Z, zs + zat(kt));
 
     // two register sets: the operands of the next group are requested before the current one is consumed
     Rec ra, rb;
@@ -1019,13 +1049,13 @@ struct Solver {
     {  // terminal knot: state only (every row, redundantly)
       const bool bx = box_at(kt);
       const double zb = is_x ? xb : 0.0;
-      if constexpr (OPEN) stg(P.Z, at(cur * N + kt), zb);
-      else stg(P.Z, zd + at(kt), zb);
+      if constexpr (OPEN) stg(P.Z, zat(cur * N + kt), zb);
+      else stg(P.Z, zd + zat(kt), zb);
       double qz;
       unsigned code;
       Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
       if (rr == 0) qh = hash_add(qh, code, kt);   // once: the rows' partial hashes are added below
-      stg(P.Qz, at(kt), is_x ? qz : 0.0);
+      stg(P.Qz, qat(kt), is_x ? qz : 0.0);
       limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
       if constexpr (!OPEN) {
         changed = changed | (is_x & (zb != t_z));
@@ -1068,8 +1098,8 @@ struct Solver {
       sfor<0, UN>([&](auto t) {
         constexpr int Tt = decltype(t)::value;
         const int k = imin(k0 + Tt, N - 2);
-        u[Tt] = ldg(P.Z, zs + at(k));
-        d[Tt] = ldg(P.Dff, at(k));
+        u[Tt] = ldg(P.Z, zs + zat(k));
+        d[Tt] = ldg(P.Dff, qat(k));
       });
       sfor<0, UN>([&](auto t) {
         constexpr int Tt = decltype(t)::value;
@@ -1157,14 +1187,14 @@ struct Solver {
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = imin(k0 + Q, N - 1);
-        z[Q] = ldg(P.Z, zs + at(k));
-        zz1[Q] = ldg(P.Z, z1 + at(k));
-        zr[Q] = ldg(P.Zref, at(kref + k));
+        z[Q] = ldg(P.Z, zs + zat(k));
+        zz1[Q] = ldg(P.Z, z1 + zat(k));
+        zr[Q] = ldg(P.Zref, rat(kref + k));
         lhi[Q] = ldg(P.Lb, lb_at(k, 0));
         llo[Q] = ldg(P.Lb, lb_at(k, 1));
         lcq[Q] = 0.0;
         if constexpr (CONES) {
-          lcq[Q] = ldg(P.Lc, at(k));
+          lcq[Q] = ldg(P.Lc, qat(k));
           if (inv) ckq[Q] = ck0;
           else con_load(k, ckq[Q]);
         }
@@ -1235,15 +1265,15 @@ struct Solver {
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = imin(k0 + Q, N - 1);
-        z[Q] = ldg(P.Z, zs + at(k));
-        zz1[Q] = ldg(P.Z, z1 + at(k));
+        z[Q] = ldg(P.Z, zs + zat(k));
+        zz1[Q] = ldg(P.Z, z1 + zat(k));
       });
       sfor<0, UN>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         const int k = k0 + Q;
         const bool on = (k >= N - 1) ? is_x : (is_x | is_u);
         const double zb = on ? __builtin_fma(alpha, zz1[Q] - z[Q], z[Q]) : 0.0;
-        stg(P.Z, at((doit & (k < N)) ? (cur ^ 1) * N + imin(k, N - 1) : 2 * N), zb);
+        stg(P.Z, zat((doit & (k < N)) ? (cur ^ 1) * N + imin(k, N - 1) : 2 * N), zb);
       });
     }
   }
@@ -1318,8 +1348,8 @@ struct Solver {
     double Sx[NX + 1];
     {
       const int k = N - 1;
-      const double z = ldg(P.Z, zs + at(k));
-      const double zr = ldg(P.Zref, at(kref + k));
+      const double z = ldg(P.Z, zs + zat(k));
+      const double zr = ldg(P.Zref, rat(kref + k));
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       double qz = lc.wf * (z - zr), hz = lc.wf;
       unsigned codeT;
@@ -1335,7 +1365,7 @@ struct Solver {
         double acolT[16];
         con_load(k, ckT);
         con_col(k, acolT);
-        cone_expand(k, ckT, acolT, is_x ? z : 0.0, ldg(P.Lc, at(k)), qz, hT);
+        cone_expand(k, ckT, acolT, is_x ? z : 0.0, ldg(P.Lc, qat(k)), qz, hT);
         sfor<0, NX>([&](auto c) { Sx[decltype(c)::value] = hT[decltype(c)::value]; });
       } else {
         sfor<0, NX>([&](auto c) {
@@ -1351,7 +1381,7 @@ struct Solver {
     bool dbig = false;
     double* my = sm;
     // operands of the knot about to be processed (loaded one knot ahead)
-    double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
+    double z = ldg(P.Z, zs + zat(N - 2)), zr = ldg(P.Zref, rat(kref + N - 2));
     double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
     double lcc = 0.0;
     // the knot's constraint table (this lane's row and column, 26+ loads from L2) is requested one knot
@@ -1359,17 +1389,24 @@ struct Solver {
     ConK ckc;
     double acolc[16];
     if constexpr (CONES) {
-      lcc = ldg(P.Lc, at(N - 2));
+      lcc = ldg(P.Lc, qat(N - 2));
       con_load(N - 2, ckc);
       con_col(N - 2, acolc);
     }
+    // The operands loaded ahead are waited for HERE, once.  hipcc's wait-count pass merges the state of the loop's two
+    // entries; with these loads still pending on the way in, the merged state made every iteration wait at its first use
+    // of them for all but the 4 youngest memory operations (`s_waitcnt vmcnt(4)` right after the body's own four loads),
+    // i.e. for the FIVE GAIN STORES of the previous knot: one store round trip per knot, the reason the pass slowed down
+    // by 40-80 % whenever the memory system was busy.
+    asm volatile("" : "+v"(z), "+v"(zr), "+v"(lhi), "+v"(llo));
+    if constexpr (CONES) asm volatile("" : "+v"(lcc));
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
-      const double zn = ldg(P.Z, zs + at(km));
-      const double zrn = ldg(P.Zref, at(kref + km));
+      const double zn = ldg(P.Z, zs + zat(km));
+      const double zrn = ldg(P.Zref, rat(kref + km));
       const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
       double lcn = 0.0;
-      if constexpr (CONES) lcn = ldg(P.Lc, at(km));
+      if constexpr (CONES) lcn = ldg(P.Lc, qat(km));
       double qz = lc.wd * (z - zr), hz = lc.wd;
       unsigned code;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
@@ -1529,7 +1566,7 @@ struct Solver {
       constexpr int A = decltype(a)::value;
       dl = (j == NX + A) ? kd[A] : dl;
     });
-    stg(P.Dff, at(kf), dl);
+    stg(P.Dff, qat(kf), dl);
     sfor<0, NU>([&](auto a) {
       constexpr int A = decltype(a)::value;
       double v = kd[A];
@@ -1566,14 +1603,14 @@ struct Solver {
     bool dbig = false;
     dV1 = 0.0;
     dV2 = 0.0;
-    double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
+    double sv = ldg(P.Qz, qat(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
     constexpr int PD = ALTRO_PD_FOSWEEP;
     struct In {
       double qz, z, kr[NU];
     };
     auto load = [&](int k, In& in) {
-      in.qz = ldg(P.Qz, at(k));
-      in.z = ldg(P.Z, zs + at(k));
+      in.qz = ldg(P.Qz, qat(k));
+      in.z = ldg(P.Z, zs + zat(k));
       sfor<0, NU>([&](auto a) { in.kr[decltype(a)::value] = ldg(P.KD, kd_at(k, decltype(a)::value)); });
     };
     // two register sets of PD knots: the operands of the next group are requested before the current one is consumed (see
@@ -1581,8 +1618,23 @@ struct Solver {
     In ra[PD], rb[PD];
     int k = N - 2;
     sfor<0, PD>([&](auto u) { load(imax(k - decltype(u)::value, 0), ra[decltype(u)::value]); });
+    // The feedforward terms of a group are stored one group LATER, after that group's operands have been waited for.  The
+    // memory counter is in order: a store issued between the loads of the next group and the wait for them is waited for
+    // as well -- issued a few instructions earlier, that was a full store round trip per group of PD knots.
+    double dst_[PD];
+    int kst = N;  // first knot of the pending stores (N: none yet -> the trash row)
+    sfor<0, PD>([&](auto u) { dst_[decltype(u)::value] = 0.0; });
+    auto flush = [&]() {
+      sfor<0, PD>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        stg(P.Dff, qat((live & (kst - U >= 0) & (kst < N)) ? kst - U : N), dst_[U]);
+      });
+    };
     auto group = [&](In (&cur_)[PD], In (&nxt)[PD]) {
       sfor<0, PD>([&](auto u) { load(imax(k - PD - decltype(u)::value, 0), nxt[decltype(u)::value]); });
+      landed_in(cur_[0].qz);   // the wait for this group's operands goes here, BEFORE the previous group's stores
+      flush();
+      kst = k;
       sfor<0, PD>([&](auto u) {
         constexpr int U = decltype(u)::value;
         const In& in = cur_[U];
@@ -1626,7 +1678,7 @@ struct Solver {
         dbig = dbig | (valid & is_u & !(dm <= 1e-9 * (1.0 + fabs(in.z))));
         dV1 += valid ? t1 : 0.0;
         dV2 += valid ? -0.5 * t1 : 0.0;
-        stg(P.Dff, at((live & valid) ? k - U : N), dl);
+        dst_[U] = dl;
         sv = valid ? (is_x ? snew : 0.0) : sv;
       });
       k -= PD;
@@ -1636,6 +1688,7 @@ struct Solver {
       if (k < 0) break;
       group(rb, ra);
     }
+    flush();
     dtiny = !row_any(dbig, lane);
     prio_base();
   }
@@ -1776,8 +1829,8 @@ struct Solver {
     double Sl[RL + 1];
     {
       const int k = N - 1;
-      const double z = ldg(P.Z, zs + at(k));
-      const double zr = ldg(P.Zref, at(kref + k));
+      const double z = ldg(P.Z, zs + zat(k));
+      const double zr = ldg(P.Zref, rat(kref + k));
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       double qz = lc.wf * (z - zr), hz = lc.wf;
       unsigned codeT;
@@ -1791,12 +1844,13 @@ struct Solver {
     fail = false;
     bool dbig = false;
     double* my = sm;
-    double z = ldg(P.Z, zs + at(N - 2)), zr = ldg(P.Zref, at(kref + N - 2));
+    double z = ldg(P.Z, zs + zat(N - 2)), zr = ldg(P.Zref, rat(kref + N - 2));
     double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
+    asm volatile("" : "+v"(z), "+v"(zr), "+v"(lhi), "+v"(llo));  // waited for once, outside the loop: see backward()
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
-      const double zn = ldg(P.Z, zs + at(km));
-      const double zrn = ldg(P.Zref, at(kref + km));
+      const double zn = ldg(P.Z, zs + zat(km));
+      const double zrn = ldg(P.Zref, rat(kref + km));
       const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
       double qz = lc.wd * (z - zr), hz = lc.wd;
       unsigned code;
@@ -1961,7 +2015,7 @@ struct Solver {
     const double thr = 0.25e-9 * P.wd[j];
     const int N = P.N;
     bool gbig = false;
-    double sv = ldg(P.Qz, at(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
+    double sv = ldg(P.Qz, qat(N - 1));  // terminal knot: l_x on the state lanes, 0 elsewhere
     // Two register sets of H knots each: the loads of group g + 1 are issued BEFORE group g is consumed.  A ring (reload slot
     // U right after knot U) looked like H knots of lead time but was not: hipcc places ONE s_waitcnt at the top of the loop
     // body that waits for every load of the ring except the youngest (vmcnt(1) with eight in flight), i.e. for loads issued a
@@ -1970,9 +2024,9 @@ struct Solver {
     constexpr int H = ALTRO_PD_ADJOINT;
     double ra[H], rb[H];
     int k = N - 2;
-    sfor<0, H>([&](auto u) { ra[decltype(u)::value] = ldg(P.Qz, at(imax(k - decltype(u)::value, 0))); });
+    sfor<0, H>([&](auto u) { ra[decltype(u)::value] = ldg(P.Qz, qat(imax(k - decltype(u)::value, 0))); });
     auto group = [&](double (&cur_)[H], double (&nxt)[H]) {
-      sfor<0, H>([&](auto u) { nxt[decltype(u)::value] = ldg(P.Qz, at(imax(k - H - decltype(u)::value, 0))); });
+      sfor<0, H>([&](auto u) { nxt[decltype(u)::value] = ldg(P.Qz, qat(imax(k - H - decltype(u)::value, 0))); });
       sfor<0, H>([&](auto u) {
         constexpr int U = decltype(u)::value;
         const bool valid = k - U >= 0;
@@ -2002,7 +2056,7 @@ struct Solver {
     const double dmax = P.o.dual_max;
     for (int k = P.box_k0; k <= P.box_k1; ++k) {
       const bool on = (k < P.N - 1) ? (is_x | is_u) : is_x;
-      const double z = ldg(P.Z, zs + at(k));
+      const double z = ldg(P.Z, zs + zat(k));
       const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
       const double nhi = fmin(fmax(lhi + mu * (z - lc.zmax), 0.0), dmax);
       const double nlo = fmin(fmax(llo + mu * (lc.zmin - z), 0.0), dmax);
@@ -2016,13 +2070,13 @@ struct Solver {
         con_load(k, ck);
         const ConMeta& cm = ck.cm;
         const bool live = (k < P.N - 1) ? (is_x | is_u) : is_x;
-        const double z = ldg(P.Z, zs + at(k));
-        const double lam = ldg(P.Lc, at(k));
+        const double z = ldg(P.Z, zs + zat(k));
+        const double lam = ldg(P.Lc, qat(k));
         const bool act = con_act(cm, k);
         const double v = con_value(live ? z : 0.0, ck.arow, ck.brow);
         const ConeEval e = cone_eval<false>(v, act ? lam : 0.0, mu, cm, act, dmax, so2);
         const bool row_on = act & ((cm.type == CT_SOC) ? (cm.pos < cm.p) : (cm.type != CT_NONE));
-        stg(P.Lc, at((upd & row_on) ? k : P.N), e.lam_new);
+        stg(P.Lc, qat((upd & row_on) ? k : P.N), e.lam_new);
       }
     }
   }
@@ -2036,7 +2090,7 @@ struct Solver {
       constexpr int C = decltype(c)::value;
       grow[C] = ldg(P.Grow, ((unsigned)inst * LW + C) * LW + j);
     });
-    const double z0 = ldg(P.Z, plane(rs->cur) + at(0));
+    const double z0 = ldg(P.Z, plane(rs->cur) + zat(0));
     double acc4[4] = {ldg(P.fvec, rowoff), 0.0, 0.0, 0.0};
     Blk<NX, NU>::GZ(acc4, z0, grow);
     const double xn = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
@@ -2122,7 +2176,7 @@ struct Solver {
               stg(P.Lb, lb_at((go & bounded) ? k : P.N, 1), 0.0);
             }
             if constexpr (CONES) {
-              for (int k = 0; k < P.N; ++k) stg(P.Lc, at(go ? k : P.N), 0.0);
+              for (int k = 0; k < P.N; ++k) stg(P.Lc, qat(go ? k : P.N), 0.0);
             }
           }
           if (begin) {
@@ -2208,7 +2262,8 @@ struct Solver {
         if ((int)blockIdx.x == P.dbg_wave && turns < 4096 && (lane & 15) == 0) {
           // per turn and row: phase | it << 4 | iters << 12 | step << 20 | outer << 28
           long long* tr = P.wave_cycles + (size_t)gridDim.x * 16 + turns;
-          const long long code = (long long)rs->phase | ((long long)(rs->it & 255) << 4) | ((long long)(rs->iters & 255) << 12) | ((long long)(rs->step & 255) << 20) | ((long long)(rs->outer & 15) << 28);
+          const long long code = (long long)rs->phase | ((long long)(rs->it & 255) << 4) | ((long long)(rs->iters & 255) << 12) | ((long long)(rs->step & 255) << 20) | ((long long)(rs->outer & 15) << 28) |
+                                 (((stamp() - t_start) >> 10) << 32);   // k-ticks since the wave started
           // four rows packed 16 bits apart would overflow: one word per row, interleaved
           P.wave_cycles[(size_t)gridDim.x * 16 + (size_t)(turns & 1023) * 4 + (lane >> 4)] = code;
           (void)tr;
@@ -2610,6 +2665,7 @@ __global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SI
   __shared__ altro::AHash hashes[128];
   const long long t0 = __builtin_amdgcn_s_memtime();
   Solver<NX, NU, CONES> s(p, rows, tiles, hashes);
+  ALTRO_STAMP(s.t_start = t0;)
   s.run(p.nsteps > 0, p.first_step, p.nsteps);
   s.finish();
   const long long t1 = __builtin_amdgcn_s_memtime();

@@ -80,6 +80,28 @@ class RankGroup:
     def gather(self, U1, status):
         return gather_results(U1, status, device=self.device)
 
+    def timed(self, fn):
+        """The timed region of every bench line: barrier + device synchronise, fn(), barrier + device synchronise;
+        returns the MAX over ranks of the wall time.  fn must leave its own device work finished (the solver
+        synchronises its HIP stream itself: it does not run on torch's current stream)."""
+        import time
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def gather_checked(self, U1, status):
+        """The one collective of a run, after the timed region: all_gather of the first controls and the status of
+        every rank's shard.  Rank r's rows must sit at [r B, (r + 1) B) of the result (a mis-ordered gather shows)."""
+        U1, status = np.asarray(U1), np.asarray(status)
+        B = U1.shape[0]
+        allU, allS = self.gather(U1, status)
+        assert allU.shape == (self.world * B,) + U1.shape[1:] and allS.shape == (self.world * B,), (allU.shape, allS.shape)
+        assert np.array_equal(allU[self.rank * B:(self.rank + 1) * B], U1)
+        assert np.array_equal(allS[self.rank * B:(self.rank + 1) * B], status)
+        return allU, allS
+
     def close(self):
         if self.world > 1:
             self.dist.barrier()

@@ -437,3 +437,41 @@ def gen_quadruped_problem(N=15, dt=0.03, vx=0.0, linearized_friction=True):
     u_hover = np.tile([0.0, 0.0, 9.81 * mass / 4.0], 4)
     return QuadrupedData(n=n, m=m, N=N, dt=dt, Q=q, R=r, x_des=x_des, u_hover=u_hover, feet=feet, inertia=inertia,
                          mass=mass, mu=mu, fz_max=fz_max, constraints=cons)
+
+
+@dataclass
+class QuadrupedBatch:
+    """A batch of quadruped MPC loops (BASELINE configs[4]): per instance a gait phase, an initial state, the per-knot
+    affine dynamics of every tick of the loop and the plant noise.  Instance i draws from its own stream keyed by
+    (seed, first_instance + i), so the shards of a multi-rank run are slices of one global batch."""
+    qp: QuadrupedData
+    t0: np.ndarray       # (B,) gait phase at tick 0
+    x0: np.ndarray       # (B, 12)
+    A: np.ndarray        # (B, T, 12, 12) blocks of absolute knots 0..T-1 (tick r's window reads r .. r + N - 2)
+    Bm: np.ndarray       # (B, T, 12, 12)
+    d: np.ndarray        # (B, T, 12)
+    noise: np.ndarray    # (steps, B, 12) unit normals
+    first_instance: int
+
+
+def gen_quadruped_batch(batch, N=40, steps=20, seed=17, first_instance=0, linearized_friction=True):
+    """altro_solver.jl:44-88 driven as a closed loop: trot gait at a random phase, start near the stance pose."""
+    qp = gen_quadruped_problem(N=N, linearized_friction=linearized_friction)
+    T = steps + N
+    sx = np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
+    t0 = np.zeros(batch)
+    x0 = np.zeros((batch, 12))
+    noise = np.zeros((steps, batch, 12))
+    A, Bm, d = np.zeros((batch, T, 12, 12)), np.zeros((batch, T, 12, 12)), np.zeros((batch, T, 12))
+    cache = {}
+    for b in range(batch):
+        rng = instance_rng(seed, first_instance + b)
+        t0[b] = rng.uniform(0.0, 0.8)
+        x0[b] = qp.x_des + rng.standard_normal(12) * sx
+        noise[:, b] = rng.standard_normal((steps, 12))
+        for t in range(T):
+            c = tuple(trot_contacts(t0[b] + t * qp.dt))
+            if c not in cache:
+                cache[c] = quadruped_linearize(qp.x_des, np.zeros(12), qp.feet, np.array(c), qp.inertia, qp.mass, qp.dt)
+            A[b, t], Bm[b, t], d[b, t] = cache[c]
+    return QuadrupedBatch(qp=qp, t0=t0, x0=x0, A=A, Bm=Bm, d=d, noise=noise, first_instance=first_instance)

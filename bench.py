@@ -151,7 +151,7 @@ def flops_first_order(n, m, N):
     return (N - 1) * (2 * n * (n + m) + 2 * n * m + 2 * m * m + 6 * m)
 
 
-def secondary_traffic(key, steps=None):
+def secondary_traffic(key, steps=None, whole=False):
     """HBM bytes of the timed launch of a secondary line from the committed rocprofv3 PMC passes
     (profiles/rNN_secondary_kernels.json, tools/profile_secondary.sh), or None.  key: (config name, kernel substring
     [, {launch configuration}: the sweep points of one kernel differ in grid and block size]);
@@ -168,20 +168,59 @@ def secondary_traffic(key, steps=None):
             continue
         for rec in ent.get("launches", []):
             if key[1] in rec.get("kernel", "") and "hbm_bytes" in rec and all(rec.get(k) == v for k, v in (key[2] if len(key) > 2 else {}).items()):
-                best = rec["hbm_bytes"]
+                best = rec if whole else rec["hbm_bytes"]
     return best
 
 
-def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None, traffic_key=None):
-    """Run W warm-up + K timed MPC steps (one fused launch) of a secondary BASELINE config on one GPU and build
-    its JSON line: same metric, roofline from HIP events on the library's stream and the measured pass counts."""
+def mfma_fraction(rec):
+    """FP64 MFMA utilisation of a profiled launch: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop / launch time / FP64 matrix peak
+    (the counter and the launch time both come from the committed rocprofv3 passes of the same command line)"""
+    if not rec or "SQ_INSTS_VALU_MFMA_MOPS_F64" not in rec or not rec.get("timed_launch_ms"):
+        return None
+    return rec["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / (rec["timed_launch_ms"] * 1e-3) / (FP64_PEAK_TFLOPS * 1e12)
+
+
+class _Solo:
+    """the rank group of a single process (no torch): what parallel.RankGroup does with world = 1"""
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, x):
+        return float(x)
+
+    def sum_over_ranks(self, v):
+        return int(v)
+
+    def gather(self, U1, status):
+        return np.asarray(U1), np.asarray(status)
+
+    def timed(self, fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    def gather_checked(self, U1, status):
+        return np.asarray(U1), np.asarray(status)
+
+
+def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, extra=None, traffic_key=None, grp=None):
+    """Run W warm-up + K timed MPC steps (one fused launch) of a secondary BASELINE config on every rank's shard and
+    build its JSON line: same metric and bracket as the headline (barrier + synchronise on both sides, MAX over ranks,
+    whole-job solves / that time), roofline from HIP events on rank 0's stream and its measured pass counts."""
+    grp = grp or _Solo()
     for i in range(W):
         mp.step(i)
-    altro.timing_reset(mp.solver)          # synchronises the library's stream (no torch here: plumbing only)
-    t0 = time.perf_counter()
-    mp.run_async(K, first=W)
-    mp.synchronize()
-    dt = time.perf_counter() - t0
+    altro.timing_reset(mp.solver)          # synchronises the library's stream
+    def run():
+        mp.run_async(K, first=W)
+        mp.synchronize()
+
+    dt = grp.timed(run)
+    # the results an MPC consumer reads each tick: the only collective, after the timed region
+    allU, allS = grp.gather_checked(altro.controls(mp.solver)[:, 0].copy(), altro.stats(mp.solver).status)
+    assert allU.shape == (grp.world * B, m), allU.shape
     ms = altro.timing_get(mp.solver)
     nb, nr, ntr = altro.work_counters(mp.solver)
     nsol, nit, nok = altro.solve_counters(mp.solver)
@@ -197,17 +236,21 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
     avg_ms = float(ms.mean())
     achieved = flops / len(ms) / (avg_ms * 1e-3) / 1e12
     executed = flops_exec / len(ms) / (avg_ms * 1e-3) / 1e12
-    out = {"metric": "MPC solves/sec (batched iLQR to tol), " + name, "value": B * K / dt, "unit": "solves/s", "n_gpus": 1,
+    out = {"metric": "MPC solves/sec (batched iLQR to tol), " + name, "value": grp.world * B * K / dt, "unit": "solves/s", "n_gpus": grp.world,
            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic", "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B},
+           "dtype": "f64", "data": "synthetic", "config": {"workload": workload, "batch_per_gpu": B, "global_batch": grp.world * B,
+                                                          "parallelism": "instances sharded over %d GPU(s), no data-path collective" % grp.world},
            "roofline": {"bound": bound, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": secondary_traffic(traffic_key, K) if traffic_key else None, "kernel": kernel, "avg_launch_ms": avg_ms,
+                        "traffic": secondary_traffic(traffic_key, K) if traffic_key else None,
+                        "mfma_frac": mfma_fraction(secondary_traffic(traffic_key, K, whole=True)) if traffic_key else None,
+                        "kernel": kernel, "avg_launch_ms": avg_ms,
                         "launches": int(len(ms)),
                         "executed": {"achieved": executed, "frac": executed / FP64_PEAK_TFLOPS},
                         "note": "achieved: SURVEY 8(d) flops_solve (measured iterations and trials x the base Riccati / rollout formulas; "
                                 "constraint-expansion flops are not counted) -- an algorithmic rate, NOT hardware utilisation: iterations "
                                 "that take their gains from memory or are confirmed by the costate sweep execute no backward pass; "
-                                "executed: the passes the kernel ran; traffic: HBM bytes of this launch from the committed PMC passes or null"},
+                                "executed: the passes the kernel ran; traffic: HBM bytes of this launch from the committed PMC passes or null; "
+                                "mfma_frac: FP64 MFMA utilisation of the same profiled launch (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / time / peak) or null"},
            "cpu_baseline": None, "solve_succeeded_frac": float(nok.sum() / max(1, nsol.sum())),
            "iterations_mean": float(nit.sum() / max(1, nsol.sum())), "backward_passes_per_solve": float(nb.sum() / (B * K)),
            "gains_from_memory_iterations_per_solve": float(nfo.sum() / (B * K)),
@@ -235,46 +278,53 @@ def _capped(mp, altro, cap, K, W, B):
             "note": "the K steps after the line's own, Altro option iterations = %d; not the reference's configuration (its scripts leave the default 1000)" % cap}
 
 
-def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
-    """BASELINE configs[2..4] on ONE GPU at their per-GPU sizes.  `--config <name>` prints them as lines of their own; the
-    default run carries short versions (<= 10 steps) inside the headline line's `secondary` list."""
+def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64), grp=None, device=0):
+    """BASELINE configs[2..4] at their per-GPU sizes.  `--config <name>` prints them as lines of their own (under
+    torch.distributed.run every rank owns a shard of the config's instances: configs[3] "65536 sharded over 8" and
+    configs[4] "16384 over 8" are 8192 and 2048 instances per GPU); the default run carries short single-GPU versions
+    (<= 10 steps) inside the headline line's `secondary` list."""
     import altro_amd_loader  # noqa: F401
     import altro_mpc_icra2021_amd as altro
     P, api, mpcm = altro.problems, altro, altro.mpc
+    grp = grp or _Solo()
+    shard0 = altro.parallel.shard_first_instance    # global index of this rank's first instance
     lines = []
 
     def done(d):
         lines.append(d)
-        if emit:
+        if emit and grp.rank == 0:
             emit(d)
 
     if which in ("rocket", "all"):   # configs[2]: rocket landing, second-order cones, N_mpc = 100, batch 4096
         B, Nm, Nt, dt = 4096, 100, 301, 0.05
         K2 = min(K, (Nt - Nm - 1 - W) // 2)
         rp = P.gen_rocket_problem(N=Nt, tf=(Nt - 1) * dt, Qfk=1e4, Rk=1.0, theta_thrust_max=5.0, theta_glideslope=45.0)
-        rng = np.random.default_rng(1)
-        x0 = np.tile(rp.x0, (B, 1)) + rng.standard_normal((B, 6)) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
-        cold = api.ALTROSolver(mpcm.constrained_problem(rp, x0), api.SolverOptions(**altro.benchmarks.ROCKET_COLD_OPTS))
+        f0 = shard0(grp.rank, B)
+        rngs = [P.instance_rng(1, f0 + b) for b in range(B)]     # one stream per global instance: shards = slices
+        x0 = np.tile(rp.x0, (B, 1)) + np.stack([r.standard_normal(6) for r in rngs]) * np.array([1, 1, 1, .3, .3, .3]) * 0.5
+        nz_rocket = np.stack([r.standard_normal((W + 2 * K2, 6)) for r in rngs], axis=1)
+        cold = api.ALTROSolver(mpcm.constrained_problem(rp, x0), api.SolverOptions(**altro.benchmarks.ROCKET_COLD_OPTS), device)
         api.solve(cold)
         Xt, Ut = api.states(cold), api.controls(cold)
         cold.close()
         tp = P.gen_rocket_problem(N=Nm, tf=dt * (Nm - 1), include_goal=False, theta_thrust_max=5.0, theta_glideslope=45.0)
         tp.Q, tp.R, tp.Qf = np.full(6, 10.0), np.full(3, 0.1), np.full(6, 10.0)
         prob = mpcm.constrained_problem(tp, Xt[:, 0].copy(), Xt[:, :Nm].copy(), Ut[:, :Nm - 1].copy(), U0=Ut[:, :Nm - 1].copy())
-        mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, rng.standard_normal((W + 2 * K2, B, 6)),
-                           (np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])))
+        mp = mpcm.TrackMPC(prob, api.SolverOptions(**altro.benchmarks.ROCKET_MPC_OPTS), Xt, Ut, nz_rocket,
+                           (np.array([1e-3] * 3 + [1e-2] * 3), np.array([0, 0, 0, 1, 1, 1])), device=device)
         mp.initial_solve()
         line = _secondary_line("rocket_landing (SOC thrust cone) N=100", "rocket_landing N_mpc=100 batch=4096 on 1 GPU (BASELINE configs[2])",
-                               "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro, traffic_key=("rocket", "solve_kernel"))
-        line["with_iteration_cap"] = _capped(mp, altro, 100, K2, W, B)
+                               "altro::solve_kernel<6,3,true>", "valu_fp64", 6, 3, Nm, B, K2, W, mp, altro, traffic_key=("rocket", "solve_kernel"), grp=grp)
+        if grp.world == 1:
+            line["with_iteration_cap"] = _capped(mp, altro, 100, K2, W, B)
         done(line)
         mp.solver.close()
     if which in ("state_dim", "all"):   # configs[3]: state-dimension sweep, m = 4, N = 50, 8192 instances per GPU
         for n in state_dims:
-            B = 8192 if n <= 32 else 2048
+            B = 8192                      # configs[3]: 65536 instances over 8 GPUs
             K3 = min(K, 10 if n <= 16 else 5)
-            pb = P.gen_random_linear_batch(B, n=n, m=4, N=50, steps=K3 + W, seed=10)
-            mp = mpcm.BatchMPC(pb)
+            pb = P.gen_random_linear_batch(B, n=n, m=4, N=50, steps=K3 + W, seed=10, first_instance=shard0(grp.rank, B))
+            mp = mpcm.BatchMPC(pb, device=device)
             mp.initial_solve()
             kern = "altro::solve_kernel<8,4>" if n == 8 else "altro_wide::wide_kernel<4>"
             # launch configuration of the point in the committed profile: one wave per four instances (n = 8), per instance
@@ -283,34 +333,24 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64)):
             tk = ("state_dim", "solve_kernel<8, 4" if n == 8 else "wide_kernel<4, true>" if n <= 16 else "wide_kernel<4, false>",
                   {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg})
             done(_secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
-                                 kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro, traffic_key=tk))
+                                 kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro, traffic_key=tk, grp=grp))
             mp.solver.close()
     if which in ("quadruped", "all"):   # configs[4]: quadruped contact-switching MPC, N = 40, 2048 instances per GPU, LTV loop on device
-        B, N = 2048, 40
+        B, N = 2048, 40                   # configs[4]: 16384 instances over 8 GPUs
         K4 = min(K, 20)
-        qp = P.gen_quadruped_problem(N=N)
-        rng = np.random.default_rng(17)
-        t0 = rng.uniform(0.0, 0.8, B)
-        x0 = qp.x_des + rng.standard_normal((B, 12)) * np.array([.02, .02, .02, .05, .05, .05, .3, .3, .1, .3, .3, .3])
-        T = W + 2 * K4 + N
-        A, Bm, d = np.zeros((B, T, 12, 12)), np.zeros((B, T, 12, 12)), np.zeros((B, T, 12))
-        cache = {}
-        for b in range(B):
-            for t in range(T):
-                c = tuple(P.trot_contacts(t0[b] + t * qp.dt))
-                if c not in cache:
-                    cache[c] = P.quadruped_linearize(qp.x_des, np.zeros(12), qp.feet, np.array(c), qp.inertia, qp.mass, qp.dt)
-                A[b, t], Bm[b, t], d[b, t] = cache[c]
+        qb = P.gen_quadruped_batch(B, N=N, steps=W + 2 * K4, seed=17, first_instance=shard0(grp.rank, B))
+        qp, x0, A, Bm, d = qb.qp, qb.x0, qb.A, qb.Bm, qb.d
         Nt = W + 2 * K4 + N + 1
         prob = mpcm.quadruped_problem(qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
         mp = mpcm.TrackMPC(prob, api.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
-                           rng.standard_normal((W + 2 * K4, B, 12)), (np.full(12, 1e-3),))
+                           qb.noise, (np.full(12, 1e-3),), device=device)
         api.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
         api.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))
         mp.initial_solve()
         line = _secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
-                               "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel"))
-        line["with_iteration_cap"] = _capped(mp, altro, 50, K4, W, B)
+                               "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel"), grp=grp)
+        if grp.world == 1:
+            line["with_iteration_cap"] = _capped(mp, altro, 50, K4, W, B)
         done(line)
         mp.solver.close()
     return lines
@@ -344,9 +384,14 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
 
     if a.config != "headline":
-        if world != 1:
-            sys.exit("secondary configs are single-GPU lines")
-        secondary_configs(a.config, a.steps, a.warmup, emit=lambda d: print(json.dumps(d), flush=True))
+        grp = None
+        if world > 1:   # one rank per GPU, each owns a shard of the config's instances (same bracket as the headline)
+            import altro_amd_loader  # noqa: F401
+            import altro_mpc_icra2021_amd as altro
+            grp = altro.parallel.RankGroup("nccl")
+        secondary_configs(a.config, a.steps, a.warmup, emit=lambda d: print(json.dumps(d), flush=True), grp=grp, device=local_rank)
+        if grp is not None:
+            grp.close()
         return
 
     cpu = None
@@ -378,16 +423,14 @@ def main():
 
     def region(first):
         """exactly K MPC steps of every instance, bracketed by barrier + synchronize on both sides; max over ranks"""
-        grp.barrier()
-        t0 = time.perf_counter()
-        i = first
-        while i < first + K:
-            n = min(spl, first + K - i)
-            mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
-            i += n
-        mp.synchronize()
-        grp.barrier()
-        return grp.max_over_ranks(time.perf_counter() - t0)
+        def run():
+            i = first
+            while i < first + K:
+                n = min(spl, first + K - i)
+                mp.run_async(n, first=i)   # n consecutive MPC steps of every instance in one launch
+                i += n
+            mp.synchronize()
+        return grp.timed(run)
 
     def preheat(ms_):
         """keep the GPU busy for ms_ milliseconds with work that touches nothing of the solver"""
@@ -419,10 +462,8 @@ def main():
     # final gather of the first controls + status (what an MPC consumer reads each tick): the only
     # collective of the run, after the timed region
     U1 = altro.controls(mp.solver)[:, 0].copy()
-    allU, allS = grp.gather(U1, st.status)
+    allU, allS = grp.gather_checked(U1, st.status)   # asserts that rank r's shard sits at rows [r B, (r + 1) B)
     assert allU.shape == (world * B, N_CTRL)
-    # rank r's shard sits at rows [r B, (r+1) B) of the gathered array (a mis-ordered gather shows here)
-    assert np.array_equal(allU[rank * B:(rank + 1) * B], U1) and np.array_equal(allS[rank * B:(rank + 1) * B], st.status)
     ok = grp.sum_over_ranks(ok)
 
     # the same K-step region R - 1 more times, back to back (later steps of the same closed loops): the spread of the number
@@ -436,7 +477,7 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not a.no_secondary:
         mp.solver.close()
-        secondary = secondary_configs("all", min(K, 10), min(W, 3), state_dims=(8, 16, 32, 64))
+        secondary = secondary_configs("all", min(K, 10), min(W, 3), state_dims=(8, 16, 32, 48, 64), device=local_rank)
 
     if rank == 0:
         n, m, N = N_STATE, N_CTRL, N_KNOT

@@ -20,7 +20,7 @@ w = int(os.environ["ALTRO_DEBUG_TRACE_WAVE"])
 wc = buf[:B // 4 * 16].reshape(-1, 16)
 print("wave", w, "total %.2fM" % (wc[w, 0] / 1e6), "#bw4 %d #lone %d #rc %d" % (wc[w, 11], wc[w, 7], wc[w, 14]))
 ph = "BOID"
-for t in range(1, 90):
+for t in range(1, 200):
     row = tr[t]
     if not row.any(): break
-    print("%3d " % t + "  ".join("%s it%d/%d st%2d o%d" % (ph[c & 15], (c >> 4) & 255, (c >> 12) & 255, (c >> 20) & 255, (c >> 28) & 15) for c in row))
+    print("%3d %6.2fM " % (t, (int(row[0]) >> 32) * 1024 / 1e6) + "  ".join("%s it%d/%d st%2d o%d" % (ph[c & 15], (c >> 4) & 255, (c >> 12) & 255, (c >> 20) & 255, (c >> 28) & 15) for c in (int(x) & 0xFFFFFFFF for x in row)))
