@@ -35,6 +35,7 @@ EXPORTS = [
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
     "altro_mpc_prepare_async", "altro_batch_benchmark_solve", "altro_mpc_set_dynamics_track",
     "altro_batch_get_confirm_counter", "altro_batch_get_reuse_counter", "altro_batch_get_polish_stats",
+    "altro_debug_set",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -142,8 +143,39 @@ def lib():
     L.altro_batch_get_polish_stats.argtypes = [H, ip, ip, dp]
     L.altro_mpc_set_dynamics_track.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32, C.c_int32]
     L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+    L.altro_debug_set.argtypes = [H, C.c_char_p, C.c_int32]
     for name in EXPORTS:
         if name != "altro_last_error":
             getattr(L, name).restype = C.c_int32
     _lib = L
     return L
+
+
+# Environment variables of the tests and measuring tools -> altro_debug_set keys.  The LIBRARY reads no environment; this
+# harness forwards these variables to its explicit entry point whenever a solver is created (api.ALTROSolver), so that
+# `ALTRO_NO_LONE=1 python tools/...` and pytest's monkeypatch.setenv keep working.  (variable, key, default, negate)
+DEBUG_ENV = [
+    ("ALTRO_NO_LONE", "no_lone", 0), ("ALTRO_NO_SHADOW", "no_shadow", 0), ("ALTRO_NO_RESYNC", "no_resync", 0),
+    ("ALTRO_NO_GROUP", "no_group", 0), ("ALTRO_NO_REUSE", "no_reuse", 0), ("ALTRO_GROUP_MAX_STEPS", "group_max_steps", 32),
+    ("ALTRO_DEBUG_TRACE_WAVE", "trace_wave", -1), ("ALTRO_FORCE_WIDE", "force_wide", 0),
+    ("ALTRO_WIDE_COMPACT", "wide_compact", -1), ("ALTRO_WIDE_COOP", "wide_coop", -1),
+    ("ALTRO_WIDE_STATIC_MASK", "wide_static_mask", -1), ("ALTRO_DEBUG_KEEP_GAINS", "keep_gains", 0),
+]
+
+
+def debug_set(key, value, handle=None):
+    """altro_debug_set(handle or NULL, key, value); raises AltroError on a refusal"""
+    L = lib()
+    rc = L.altro_debug_set(handle, key.encode(), int(value))
+    if rc:
+        raise AltroError(rc, (L.altro_last_error(handle) or b"").decode())
+
+
+def sync_debug_env():
+    """forward the ALTRO_* diagnostic variables of the environment to altro_debug_set (defaults where unset)"""
+    for var, key, default in DEBUG_ENV:
+        v = os.environ.get(var)
+        debug_set(key, int(v) if v not in (None, "") else default)
+    gm = os.environ.get("ALTRO_GROUP_MODE")     # after no_group: a slot order switches grouping on
+    if gm not in (None, ""):
+        debug_set("group_mode", int(gm))

@@ -163,6 +163,7 @@ class ALTROSolver:
         self.opts = opts if opts is not None else SolverOptions()
         dims = _lib.Dims(B, n, m, prob.N)
         h = C.c_void_p()
+        _lib.sync_debug_env()   # the tests' / tools' ALTRO_* switches reach the library through altro_debug_set, not getenv
         rc = L.altro_batch_create(C.byref(dims), C.byref(self.opts), device, C.byref(h))
         if rc:
             raise AltroError(rc, L.altro_last_error(None).decode())

@@ -24,6 +24,20 @@ using altro::LW;
 
 static thread_local std::string g_create_err;
 
+// Diagnostic switches (altro_debug_set, include/altro_batch.h).  The library reads NOTHING from the environment: a test or
+// a measuring tool that wants a scheduling feature off says so through the entry point -- with a null handle for the
+// handles this thread creates afterwards, with a handle for that handle.
+struct DebugSwitches {
+  int lone = 1, shadow = 1, resync = 1, reuse = 1;
+  int group = 1;             // 0 off, 1 sorted, 2-4: other slot orders (k_group_rank)
+  int group_max_steps = 32;
+  int trace_wave = -1;       // -DALTRO_PHASE_STAMPS builds
+  int force_wide = 0;        // every (n, m) on the one-wave-per-instance backend
+  int keep_gains = 0;        // -DALTRO_DEBUG builds only
+  int wide_compact = -1, wide_coop = -1, wide_static_mask = -1;   // -1: the backend's default
+};
+static thread_local DebugSwitches g_dbg;
+
 struct altro_handle {
   altro_wide::WideBackend* wide = nullptr;  // set: this handle runs on the one-wave-per-instance kernel
   altro_dims d{};
@@ -56,17 +70,18 @@ struct altro_handle {
   int* noise_grp = nullptr;
   int noise_mode = 0;
   int mpc_shift = 1;
-  int reuse = 1;  // gain reuse (solve_dpp16.h fosweep); ALTRO_NO_REUSE=1 at create time switches it off (tests)
-  int lone = 1;  // backward_lone (solve_dpp16.h); ALTRO_NO_LONE=1 at create time switches it off (tests: lone == four-row pass bit for bit)
-  int group_max_steps = 32;  // fused launches of more steps are not grouped (ALTRO_GROUP_MAX_STEPS at create time: diagnostic)
-  int shadow = 1;  // ALTRO_NO_SHADOW=1 at create time: rows that sit a phase out keep their own instance (solve_dpp16.h shadow_enter)
+  // scheduling switches (altro_debug_set; the defaults are the product's behaviour)
+  int reuse = 1;  // gain reuse (solve_dpp16.h fosweep); "no_reuse" switches it off (tests)
+  int lone = 1;  // backward_lone (solve_dpp16.h); "no_lone" switches it off (tests: lone == four-row pass bit for bit)
+  int group_max_steps = 32;  // fused launches of more steps are not grouped ("group_max_steps": diagnostic)
+  int shadow = 1;  // "no_shadow": rows that sit a phase out keep their own instance (solve_dpp16.h shadow_enter)
   int* cur = nullptr;
   int *perm = nullptr, *gscore = nullptr;  // [Bp] wave slot -> instance of a grouped MPC launch, and its sort key
-  bool debug_keep_gains = false;           // ALTRO_DEBUG_KEEP_GAINS=1 at create time: the setters do NOT drop the stored gains (exists
-                                           // to show that the tests notice stale gains; never set in production)
-  int group = 1;                           // ALTRO_NO_GROUP=1 at create time: identity
-  int dbg_wave = -1;                       // ALTRO_DEBUG_TRACE_WAVE (diagnostic builds only)
-  int resync = 1;                          // ALTRO_NO_RESYNC=1 at create time: rows never wait for their wave-mates
+  bool debug_keep_gains = false;           // "keep_gains" (-DALTRO_DEBUG builds only): the setters do NOT drop the stored gains
+                                           // (exists to show that the tests notice stale gains)
+  int group = 1;                           // "no_group": identity; "group_mode": other slot orders
+  int dbg_wave = -1;                       // "trace_wave" (diagnostic builds only)
+  int resync = 1;                          // "no_resync": rows never wait for their wave-mates
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
   double* stage = nullptr;  // device staging buffer for host<->device layout conversion
@@ -542,8 +557,64 @@ static int32_t guard(altro_handle* h, F&& body) noexcept {
   }
 }
 
+static void apply_wide_switches(altro_wide::WideBackend* wb) {
+  wb->debug_keep_gains = g_dbg.keep_gains != 0;
+  if (g_dbg.wide_compact >= 0) wb->compact_np_max = g_dbg.wide_compact;
+  if (g_dbg.wide_coop >= 0) wb->coop_mode = g_dbg.wide_coop != 0 ? 1 : 0;
+  if (g_dbg.wide_static_mask >= 0) wb->static_mask = g_dbg.wide_static_mask;
+}
+
 // ------------------------------------------------------------------ C-ABI
 extern "C" {
+
+int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value) {
+  return guard(h, [&]() -> int32_t {
+    if (!key) return ALTRO_ERR_INVALID_ARG;
+    const std::string k(key);
+    auto bad = [&](int32_t code, const char* msg) -> int32_t {
+      if (h) h->err = msg; else g_create_err = msg;
+      return code;
+    };
+    if (k == "keep_gains") {
+#ifdef ALTRO_DEBUG
+      if (h) { if (h->wide) h->wide->debug_keep_gains = value != 0; else h->debug_keep_gains = value != 0; }
+      else g_dbg.keep_gains = value != 0;
+      return ALTRO_OK;
+#else
+      if (value == 0) return ALTRO_OK;
+      return bad(ALTRO_ERR_UNSUPPORTED, "keep_gains exists in -DALTRO_DEBUG builds of the library only");
+#endif
+    }
+    // create-time switches: which backend, and the LDS carve-up of the one-wave-per-instance backend
+    int* pre = k == "force_wide" ? &g_dbg.force_wide : k == "wide_compact" ? &g_dbg.wide_compact : k == "wide_coop" ? &g_dbg.wide_coop
+             : k == "wide_static_mask" ? &g_dbg.wide_static_mask : nullptr;
+    if (pre) {
+      if (h) return bad(ALTRO_ERR_STATE, "this switch is read when a handle is created: pass a null handle before altro_batch_create");
+      *pre = value;
+      return ALTRO_OK;
+    }
+    DebugSwitches tmp;
+    DebugSwitches& d = h ? tmp : g_dbg;
+    if (h) { tmp.lone = h->lone; tmp.shadow = h->shadow; tmp.resync = h->resync; tmp.reuse = h->reuse; tmp.group = h->group;
+             tmp.group_max_steps = h->group_max_steps; tmp.trace_wave = h->dbg_wave; }
+    if (k == "no_lone") d.lone = value ? 0 : 1;
+    else if (k == "no_shadow") d.shadow = value ? 0 : 1;
+    else if (k == "no_resync") d.resync = value ? 0 : 1;
+    else if (k == "no_reuse") d.reuse = value ? 0 : 1;
+    else if (k == "no_group") d.group = value ? 0 : 1;
+    else if (k == "group_mode") { if (value < 0 || value > 4) return bad(ALTRO_ERR_INVALID_ARG, "group_mode is 0..4"); d.group = value; }
+    else if (k == "group_max_steps") d.group_max_steps = value;
+    else if (k == "trace_wave") d.trace_wave = value;
+    else return bad(ALTRO_ERR_INVALID_ARG, "unknown switch");
+    if (h && !h->wide) {
+      const bool reuse_changed = h->reuse != tmp.reuse;
+      h->lone = tmp.lone; h->shadow = tmp.shadow; h->resync = tmp.resync; h->reuse = tmp.reuse; h->group = tmp.group;
+      h->group_max_steps = tmp.group_max_steps; h->dbg_wave = tmp.trace_wave;
+      if (reuse_changed) { HIPCHK(h, hipSetDevice(h->device)); return drop_gains(h); }
+    }
+    return ALTRO_OK;
+  });
+}
 
 int32_t altro_default_opts(altro_opts* o) {
   return guard(nullptr, [&]() -> int32_t {
@@ -596,9 +667,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     *out = nullptr;
     if (dims->batch < 1 || dims->n < 1 || dims->m < 1 || dims->N < 3) { g_create_err = "bad dims"; return ALTRO_ERR_INVALID_ARG; }
     // (n, m) of the 16-lane kernel set run there; everything else up to n <= 64, m <= 32 runs on the
-    // one-wave-per-instance MFMA kernel (ALTRO_FORCE_WIDE=1 sends every size there: used by the tests)
-    const char* fw = getenv("ALTRO_FORCE_WIDE");
-    const bool use_wide = !supported_dims(dims->n, dims->m) || (fw && fw[0] == '1');
+    // one-wave-per-instance MFMA kernel (altro_debug_set(NULL, "force_wide", 1) sends every size there: used by the tests)
+    const bool use_wide = !supported_dims(dims->n, dims->m) || g_dbg.force_wide != 0;
     if (use_wide && !altro_wide::WideBackend::supports(dims->n, dims->m)) {
       g_create_err = "unsupported (n, m): the wide kernel holds n <= 64, m <= 32";
       return ALTRO_ERR_UNSUPPORTED;
@@ -625,6 +695,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       hw->d = *dims;
       hw->o = o0;
       hw->device = device;
+      apply_wide_switches(wb);
       const int rc = wb->create(dims, &o0, device);
       if (rc) {
         g_create_err = wb->err;
@@ -647,15 +718,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->d = *dims;
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
-    { const char* nl = getenv("ALTRO_NO_LONE"); h->lone = (nl && nl[0] == '1') ? 0 : 1; }
-    { const char* nsh = getenv("ALTRO_NO_SHADOW"); h->shadow = (nsh && nsh[0] == '1') ? 0 : 1; }
-    { const char* gms = getenv("ALTRO_GROUP_MAX_STEPS"); if (gms) h->group_max_steps = atoi(gms); }
-    { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); h->debug_keep_gains = kg && kg[0] == '1'; }
-    { const char* dw = getenv("ALTRO_DEBUG_TRACE_WAVE"); h->dbg_wave = dw ? atoi(dw) : -1; }
-    { const char* ns = getenv("ALTRO_NO_RESYNC"); h->resync = (ns && ns[0] == '1') ? 0 : 1; }
-    { const char* ng = getenv("ALTRO_NO_GROUP"); h->group = (ng && ng[0] == '1') ? 0 : 1; }
-    { const char* gm = getenv("ALTRO_GROUP_MODE"); if (gm && gm[0] >= '0' && gm[0] <= '4') h->group = gm[0] - '0'; }
-    { const char* nr = getenv("ALTRO_NO_REUSE"); h->reuse = (nr && nr[0] == '1') ? 0 : 1; }
+    h->lone = g_dbg.lone; h->shadow = g_dbg.shadow; h->resync = g_dbg.resync; h->reuse = g_dbg.reuse; h->group = g_dbg.group;
+    h->group_max_steps = g_dbg.group_max_steps; h->dbg_wave = g_dbg.trace_wave; h->debug_keep_gains = g_dbg.keep_gains != 0;
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {
       g_create_err = std::string(what) + ": " + hipGetErrorString(er);
@@ -837,8 +901,11 @@ static int migrate_to_wide(altro_handle* h) {
   if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
     FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
                                    "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
+  if (h->o.projected_newton)   // (create and set_options refuse the same combination: no polish on this backend, and no silent skip)
+    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)");
   altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
   if (!wb) FAIL(h, ALTRO_ERR_INTERNAL, "out of host memory");
+  apply_wide_switches(wb);
   // the wide backend is created BEFORE the 16-lane one is released: if it cannot be (e.g. no device
   // memory for its arrays) the handle stays a working 16-lane handle and only this call fails
   const int rc = wb->create(&h->d, &h->o, h->device);
@@ -1234,8 +1301,10 @@ int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
   });
 }
 
-// solve!(::ProjectedNewtonSolver) after the AL kernel of a plain solve (altro_opts.projected_newton)
-static int launch_polish(altro_handle* h) {
+// solve!(::ProjectedNewtonSolver) after the AL kernel of a plain solve (altro_opts.projected_newton).
+// prepare_polish: every check and allocation the polish needs -- run BEFORE a launch takes its slot of the timing ring, so
+// that a failure leaves no slot with a start event and no end event.
+static int prepare_polish(altro_handle* h) {
   const size_t Bp = h->Bp, N = h->d.N;
   int nbounded = 0;
   for (int j = 0; j < LW; ++j) nbounded += h->bslot_h[j] >= 0 ? 1 : 0;
@@ -1256,6 +1325,11 @@ static int launch_polish(altro_handle* h) {
     HIPCHK(h, hipMalloc(&h->pnrinfo, Bp * N * bm * sizeof(int)));
     h->pn_bm = bm;
   }
+  return ALTRO_OK;
+}
+
+static int launch_polish(altro_handle* h) {
+  const int bm = h->pn_bm;
   altro_pn::PnParams q{};
   q.B = h->d.batch; q.Bp = h->Bp; q.N = h->d.N; q.Nt = h->Nt; q.n = h->d.n; q.m = h->d.m; q.bm = bm;
   q.box_k0 = h->box_k0; q.box_k1 = h->box_k1; q.ncrows = h->ncrows;
@@ -1280,17 +1354,21 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   h->con_locked = true;
   const int last_kref = nsteps > 0 ? first_step + nsteps : h->kref;
   if (last_kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
+  // everything that can refuse the launch comes before it takes a slot of the timing ring
+  if (h->o.projected_newton && nsteps > 0)
+    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
+                                   "(every MPC script of the reference sets projected_newton = false)");
+  if (h->o.projected_newton && (rc = prepare_polish(h))) return rc;
+  if (!supported_dims(h->d.n, h->d.m)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
   hipEvent_t h0, h1;
   HIPCHK(h, h->ring.next(&h0, &h1));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   HIPCHK(h, hipEventRecord(h0, h->stream));
-  if (h->o.projected_newton && nsteps > 0)
-    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
-                                   "(every MPC script of the reference sets projected_newton = false)");
   rc = launch_solve(h, first_step, nsteps);
-  if (rc) return rc;
-  if (h->o.projected_newton && (rc = launch_polish(h))) return rc;
+  if (!rc && h->o.projected_newton) rc = launch_polish(h);
+  // (a launch that failed after all -- a HIP error -- still closes its slot: every slot handed out has both events)
   HIPCHK(h, hipEventRecord(h1, h->stream));
+  if (rc) return rc;
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
   if (nsteps > 0) h->kref = first_step + nsteps;
@@ -1733,6 +1811,9 @@ int32_t altro_batch_benchmark_solve(altro_handle* h, int32_t samples, int32_t ev
     HIPCHK(h, hipGetLastError());
     auto one = [&]() -> int {  // initial_trajectory!(solver, Z0); solve!(solver)
       hipLaunchKernelGGL(k_plane_copy, grid, dim3(256), 0, h->stream, h->Z, h->Zsave, h->cur, plane, h->Bp, h->d.N, 0);
+      // every evaluation recomputes its gains, as an evaluation of the reference's `@benchmark solve!` does (the gains of
+      // the previous evaluation would otherwise serve the next one: same start, same active sets)
+      if (int rcd = drop_gains(h)) return rcd;
       return enqueue_solve(h, 0, 0);
     };
     int rc = one();  // BenchmarkTools' warm-up evaluation

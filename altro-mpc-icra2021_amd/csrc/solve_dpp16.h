@@ -74,6 +74,13 @@
 // advances at 0.73 of the speed it reaches alone.  0 = off.
 #define ALTRO_PRIO_HARD 2
 #endif
+#ifndef ALTRO_PRIO_HEAVY
+// Issue priority of the waves in the upper half of a GROUPED launch (SolveParams::perm: instances sorted by the backward
+// passes they are expected to need).  With two waves per SIMD the dispatcher pairs block i with block i + grid / 2, i.e. a
+// pass-free wave with a pass-heavy one; the pass-free wave finishes its steps in a quarter of the launch either way, the
+// pass-heavy one is the launch's critical path: while they share the SIMD it should issue first.  0 = off.
+#define ALTRO_PRIO_HEAVY 0   // measured 2 and 3 over twelve windows: single windows -5 %, one +13 % (its slowest wave sat in the lower half), mean unchanged
+#endif
 #ifndef ALTRO_PRIO_LAG
 #define ALTRO_PRIO_LAG 0  // measured 4 and 8 on the headline: within run-to-run noise of 0 (off)
 #endif
@@ -395,6 +402,7 @@ struct Solver {
   RowState* rs;  // this lane's row state (LDS)
   double* sm;    // this row's 16 x 17 transpose tile (LDS)
   bool hard_wave = false;  // wave-uniform: a row of this wave is in a hard solve (see ALTRO_PRIO_HARD)
+  bool heavy_half = false; // wave-uniform: upper half of a grouped launch (see ALTRO_PRIO_HEAVY)
   int turns = 0;           // turns of the wave loop so far
   int n_lone = 0;          // backward passes of this launch that ran as backward_lone (diagnostic, wave_cycles[7])
 #ifdef ALTRO_DIAG_REUSE
@@ -423,6 +431,7 @@ struct Solver {
     j = lane & 15;
     inst = blockIdx.x * IPW + (lane >> 4);
     if (P.perm != nullptr) inst = P.perm[inst];
+    heavy_half = (P.perm != nullptr) && (2u * blockIdx.x >= gridDim.x);
     rs = rows + (lane >> 4);
     sm = tiles + (lane >> 4) * (LW * (LW + 1));
     is_x = j < NX;
@@ -529,10 +538,12 @@ struct Solver {
 
   __device__ __forceinline__ void prio_serial() const {
     if (ALTRO_PRIO_HARD > 0 && hard_wave) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HARD < 3 ? ALTRO_PRIO_HARD + 1 : 3);
+    else if (ALTRO_PRIO_HEAVY > 0 && heavy_half) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HEAVY);
     else __builtin_amdgcn_s_setprio(ALTRO_PRIO_SERIAL);
   }
   __device__ __forceinline__ void prio_base() const {
     if (ALTRO_PRIO_HARD > 0 && hard_wave) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HARD);
+    else if (ALTRO_PRIO_HEAVY > 0 && heavy_half) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HEAVY);
     else __builtin_amdgcn_s_setprio(0);
   }
 
@@ -2325,6 +2336,7 @@ struct Solver {
             }
           }
           bool bwrow = inner && !gconf && !fo;  // rows that run the backward pass of this iteration
+          if (bwrow) rs->nbw += 1;  // once per iteration (a pass restarted with more regularisation is the same iteration's pass)
           // backward pass (with regularisation restarts)
           while (wave_any(bwrow)) {
             bool fail;
@@ -2367,7 +2379,6 @@ struct Solver {
               }
             }
             ALTRO_STAMP(const long long te = stamp() - ts; if (nbwr == 1 && !CONES && P.lone && !with_rho) t_bl += te; else { t_bw += te; c_bw++; })
-            if (bwrow) rs->nbw += 1;
             fail = row_any(fail, lane) && bwrow;
             double rho = rs->rho, drho = rs->drho;
             if (bwrow) rs->kmu = (!fail && rho == 0.0) ? rs->mu : -1.0;

@@ -2359,12 +2359,12 @@ struct Solver {
           }
         }
       }
+      if (!gconf && !swept) nbw++;   // once per iteration: a pass restarted with more regularisation is the same iteration's pass
       while (!gconf && !swept) {  // regularisation restarts
         const bool plain = rho == 0.0;
         WSTAMP(const long long ts = wstamp();)
         const bool fail = backward(dV1, dV2);
         WSTAMP(t_bw += wstamp() - ts;)
-        nbw++;
         block_sync();  // phase end: gains written to global memory are read by other lanes in the rollout
         if (!fail) {
           bw_plain = plain;

@@ -57,9 +57,9 @@ struct WideBackend {
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
   unsigned* bwst = nullptr;   // [B][136] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
-  int coop_mode = -1, static_mask = 7;  // ALTRO_WIDE_COOP, ALTRO_WIDE_STATIC_MASK at create time
+  int coop_mode = -1, static_mask = 7;  // altro_debug_set "wide_coop", "wide_static_mask" (before create)
   int compact_np_max = 48;  // wide_compact: the LDS carve-up with Qux and K inside W, for padded state dimensions up to this
-  bool debug_keep_gains = false;  // ALTRO_DEBUG_KEEP_GAINS=1 at create time: stale gains are kept (exists to show that the tests notice them)
+  bool debug_keep_gains = false;  // altro_debug_set "keep_gains" (-DALTRO_DEBUG builds only): stale gains are kept (exists to show that the tests notice them)
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
   std::vector<hipEvent_t> bench_ev;
@@ -112,11 +112,10 @@ struct WideBackend {
     d = *dims;
     o = *opts;
     device = dev;
-    { const char* kg = getenv("ALTRO_DEBUG_KEEP_GAINS"); debug_keep_gains = kg && kg[0] == '1'; }
-    // diagnostic switches, read once here (never on the launch path)
-    if (const char* e = getenv("ALTRO_WIDE_COMPACT")) compact_np_max = atoi(e);  // 0 = never, 32 / 48 = up to that padded n
-    if (const char* e = getenv("ALTRO_WIDE_COOP")) coop_mode = atoi(e) != 0 ? 1 : 0;  // cooperative blocks: 0 = never, 1 = every size with n or m > 16
-    if (const char* e = getenv("ALTRO_WIDE_STATIC_MASK")) static_mask = atoi(e);     // which uses of time-invariant constraint tables stay in LDS
+    // (diagnostic switches -- compact_np_max: 0 = never, 32 / 48 = up to that padded n; coop_mode: cooperative blocks 0 = never,
+    //  1 = every size with n or m > 16; static_mask: which uses of time-invariant constraint tables stay in LDS;
+    //  debug_keep_gains -- are members set by the caller from altro_debug_set() before create(): nothing is read from the
+    //  environment)
     WCHK(hipSetDevice(device));
     const Lds L = lds_layout(d.n, d.m, kMaxP);
     (void)L;
@@ -524,6 +523,7 @@ struct WideBackend {
     auto one = [&]() -> int {  // initial_trajectory!(solver, Z0); solve!(solver)
       hipLaunchKernelGGL(k_scatter_plane, gx, dim3(256), 0, stream, X, Xsave, cur, lx, (int)B);
       hipLaunchKernelGGL(k_scatter_plane, gu, dim3(256), 0, stream, U, Usave, cur, lu, (int)B);
+      gains_valid = false;   // every evaluation recomputes its gains, as the reference's `@benchmark solve!` does
       return enqueue(0, 0, 0);
     };
     int rc = one();  // BenchmarkTools' warm-up evaluation

@@ -343,6 +343,19 @@ int32_t altro_mpc_run_async(altro_handle* h, int32_t first_step, int32_t nsteps)
 /* x0 currently installed: [batch][n] */
 int32_t altro_batch_get_initial_state(altro_handle* h, double* x0);
 
+/* Diagnostic switches (no Julia counterpart: Altro.jl has no scheduling to switch).  The library reads nothing from the
+ * environment; a test or a measuring tool that wants one of the kernels' scheduling features off -- to show that it
+ * changes no result, or to time it -- says so here.  h == NULL: for the handles THIS THREAD creates afterwards;
+ * otherwise for that handle, from its next launch on.  Keys (value 0 restores the default):
+ *   "no_lone", "no_shadow", "no_resync", "no_group", "no_reuse"   one scheduling feature of the 16-lane kernels off
+ *   "group_mode" 0..4, "group_max_steps", "trace_wave"              slot order of a grouped launch / diagnostic builds
+ *   "force_wide", "wide_compact", "wide_coop", "wide_static_mask"   read at altro_batch_create: NULL handle only
+ *   "keep_gains"   the setters stop dropping the stored gains (the product then returns results from STALE gains: it
+ *                  exists to show that the tests notice).  Compiled into -DALTRO_DEBUG builds only; a release build
+ *                  answers ALTRO_ERR_UNSUPPORTED.
+ * Unknown key: ALTRO_ERR_INVALID_ARG. */
+int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value);
+
 /* the handle's hipStream_t, for callers that order their own device work after a solve */
 int32_t altro_batch_get_stream(altro_handle* h, void** stream);
 
