@@ -35,7 +35,7 @@ EXPORTS = [
     "altro_mpc_step_async", "altro_batch_get_initial_state", "altro_batch_get_stream",
     "altro_mpc_prepare_async", "altro_batch_benchmark_solve", "altro_mpc_set_dynamics_track",
     "altro_batch_get_confirm_counter", "altro_batch_get_reuse_counter", "altro_batch_get_polish_stats",
-    "altro_debug_set",
+    "altro_debug_set", "altro_batch_get_polish_dual_residuals",
 ]
 """every symbol include/altro_batch.h declares"""
 
@@ -144,6 +144,7 @@ def lib():
     L.altro_mpc_set_dynamics_track.argtypes = [H, dp, dp, dp, C.c_int32, C.c_int32, C.c_int32]
     L.altro_batch_benchmark_solve.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     L.altro_debug_set.argtypes = [H, C.c_char_p, C.c_int32]
+    L.altro_batch_get_polish_dual_residuals.argtypes = [H, dp, dp, ip]
     for name in EXPORTS:
         if name != "altro_last_error":
             getattr(L, name).restype = C.c_int32

@@ -412,6 +412,15 @@ def polish_stats(solver):
     return ran, failed, res
 
 
+def polish_dual_residuals(solver):
+    """(before, after, failed) of the polish's multiplier projection, per instance: the stationarity residual
+    ||g + D' lam||_2 with the AL duals and with the projected multipliers (altro_batch_get_polish_dual_residuals)."""
+    a, b = np.zeros(solver.B), np.zeros(solver.B)
+    f = np.zeros(solver.B, dtype=np.int32)
+    solver._chk(solver._L.altro_batch_get_polish_dual_residuals(solver.h, _p(a), _p(b), f.ctypes.data_as(C.POINTER(C.c_int32))))
+    return a, b, f
+
+
 def reuse_counter(solver):
     """iterations per instance (since timing_reset) that took their gains from memory instead of running a backward
     pass (altro_batch_get_reuse_counter)."""

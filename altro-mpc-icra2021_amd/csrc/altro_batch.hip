@@ -61,8 +61,8 @@ struct altro_handle {
   altro::AHash* ahash = nullptr;  // [Bp][16] active set of the backward pass behind the gains in KD (gain reuse, solve_dpp16.h)
   long long* n_fo = nullptr;
   // projected-Newton polish (pn_polish.h): per-instance results and the workspace, allocated by the first solve that asks for it
-  int *pn_ran = nullptr, *pn_failed = nullptr;
-  double* pn_res = nullptr;
+  int *pn_ran = nullptr, *pn_failed = nullptr, *pn_dfail = nullptr;
+  double *pn_res = nullptr, *pn_dres0 = nullptr, *pn_dres = nullptr;
   double *pnE = nullptr, *pndv = nullptr, *pnLd = nullptr, *pnLo = nullptr, *pnvec = nullptr, *pntz = nullptr;
   int *pnnb = nullptr, *pnnst = nullptr, *pnrinfo = nullptr;
   int pn_bm = 0;
@@ -691,7 +691,6 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
       } wo{hw, wb};
       altro_opts o0;
       if (opts) o0 = *opts; else altro_default_opts(&o0);
-      if (o0.projected_newton) { g_create_err = "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)"; return ALTRO_ERR_UNSUPPORTED; }
       hw->d = *dims;
       hw->o = o0;
       hw->device = device;
@@ -791,6 +790,12 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->pn_ran, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->pn_failed, Bp * sizeof(int)));
     CCHK(hipMalloc(&h->pn_res, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->pn_dfail, Bp * sizeof(int)));
+    CCHK(hipMalloc(&h->pn_dres0, Bp * sizeof(double)));
+    CCHK(hipMalloc(&h->pn_dres, Bp * sizeof(double)));
+    CCHK(hipMemsetAsync(h->pn_dfail, 0, Bp * sizeof(int), h->stream));
+    CCHK(hipMemsetAsync(h->pn_dres0, 0, Bp * sizeof(double), h->stream));
+    CCHK(hipMemsetAsync(h->pn_dres, 0, Bp * sizeof(double), h->stream));
     CCHK(hipMemsetAsync(h->pn_ran, 0, Bp * sizeof(int), h->stream));
     CCHK(hipMemsetAsync(h->pn_failed, 0, Bp * sizeof(int), h->stream));
     CCHK(hipMemsetAsync(h->pn_res, 0, Bp * sizeof(double), h->stream));
@@ -868,7 +873,7 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
                    (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz,
                    (void**)&h->Dff, (void**)&h->ahash, (void**)&h->kmu, (void**)&h->n_fo, (void**)&h->perm, (void**)&h->gscore,
-                   (void**)&h->pn_ran, (void**)&h->pn_failed, (void**)&h->pn_res, (void**)&h->pnE, (void**)&h->pndv, (void**)&h->pnLd, (void**)&h->pnLo,
+                   (void**)&h->pn_ran, (void**)&h->pn_failed, (void**)&h->pn_res, (void**)&h->pn_dfail, (void**)&h->pn_dres0, (void**)&h->pn_dres, (void**)&h->pnE, (void**)&h->pndv, (void**)&h->pnLd, (void**)&h->pnLo,
                    (void**)&h->pnvec, (void**)&h->pntz, (void**)&h->pnnb, (void**)&h->pnnst, (void**)&h->pnrinfo};
   for (void** p : ptrs)
     if (*p) { hipFree(*p); *p = nullptr; }
@@ -901,8 +906,6 @@ static int migrate_to_wide(altro_handle* h) {
   if (h->have_cost || h->have_ref || h->have_dyn || h->ncon > 0 || h->timed)
     FAIL(h, ALTRO_ERR_UNSUPPORTED, "per-knot dynamics on an (n, m) of the 16-lane kernel set: call altro_batch_set_dynamics "
                                    "first after altro_batch_create (or set ALTRO_FORCE_WIDE=1)");
-  if (h->o.projected_newton)   // (create and set_options refuse the same combination: no polish on this backend, and no silent skip)
-    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)");
   altro_wide::WideBackend* wb = new (std::nothrow) altro_wide::WideBackend();
   if (!wb) FAIL(h, ALTRO_ERR_INTERNAL, "out of host memory");
   apply_wide_switches(wb);
@@ -1291,7 +1294,6 @@ int32_t altro_batch_shift_fill(altro_handle* h, int32_t primal, int32_t dual) {
 int32_t altro_batch_set_options(altro_handle* h, const altro_opts* o) {
   return guard(h, [&]() -> int32_t {
     if (h && h->wide && o) {
-      if (o->projected_newton) FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton: the polish is built for the 16-lane backend (n + m <= 16, time-invariant dynamics)");
       h->wide->o = *o; h->wide->gains_valid = false; h->o = *o; return ALTRO_OK;
     }
     if (!h || !o) return ALTRO_ERR_INVALID_ARG;
@@ -1319,7 +1321,7 @@ static int prepare_polish(altro_handle* h) {
     HIPCHK(h, hipMalloc(&h->pnLd, Bp * N * bm * bm * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->pnLo, Bp * N * bm * bm * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->pnvec, Bp * 6 * N * bm * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->pntz, Bp * N * LW * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pntz, Bp * 3 * N * LW * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->pnnb, Bp * N * sizeof(int)));
     HIPCHK(h, hipMalloc(&h->pnnst, Bp * N * sizeof(int)));
     HIPCHK(h, hipMalloc(&h->pnrinfo, Bp * N * bm * sizeof(int)));
@@ -1338,6 +1340,8 @@ static int launch_polish(altro_handle* h) {
   q.Acon = h->Acon; q.bcon = h->bcon; q.cmeta = h->cmeta;
   q.Z = h->Z; q.Zref = h->Zref; q.kref = h->kref; q.cur = h->cur; q.status = h->status; q.cost = h->cost; q.cmax = h->cmax;
   q.pn_ran = h->pn_ran; q.pn_failed = h->pn_failed; q.pn_res = h->pn_res;
+  q.Lb = h->Lb; q.Lc = h->Lc; q.bslot = h->bslot; q.nbp = h->nbp;
+  q.pn_dfail = h->pn_dfail; q.pn_dres0 = h->pn_dres0; q.pn_dres = h->pn_dres;
   q.E = h->pnE; q.dv = h->pndv; q.Ld = h->pnLd; q.Lo = h->pnLo; q.vec = h->pnvec; q.tz = h->pntz;
   q.nb = h->pnnb; q.nst = h->pnnst; q.rinfo = h->pnrinfo;
   q.o = h->o;
@@ -1631,12 +1635,7 @@ int32_t altro_batch_get_polish_stats(altro_handle* h, int32_t* ran, int32_t* fai
   return guard(h, [&]() -> int32_t {
     if (!h) return ALTRO_ERR_INVALID_ARG;
     const size_t B = h->d.batch;
-    if (h->wide) {  // the one-wave-per-instance backend has no polish: nothing ran
-      if (ran) std::memset(ran, 0, B * sizeof(int32_t));
-      if (failed) std::memset(failed, 0, B * sizeof(int32_t));
-      if (residual) std::memset(residual, 0, B * sizeof(double));
-      return ALTRO_OK;
-    }
+    if (h->wide) { const int rc_ = h->wide->polish_stats(ran, failed, residual); if (rc_) h->err = h->wide->err; return rc_; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->o.projected_newton) {
@@ -1648,6 +1647,26 @@ int32_t altro_batch_get_polish_stats(altro_handle* h, int32_t* ran, int32_t* fai
     if (ran) HIPCHK(h, hipMemcpy(ran, h->pn_ran, B * sizeof(int), hipMemcpyDeviceToHost));
     if (failed) HIPCHK(h, hipMemcpy(failed, h->pn_failed, B * sizeof(int), hipMemcpyDeviceToHost));
     if (residual) HIPCHK(h, hipMemcpy(residual, h->pn_res, B * sizeof(double), hipMemcpyDeviceToHost));
+    return ALTRO_OK;
+  });
+}
+
+int32_t altro_batch_get_polish_dual_residuals(altro_handle* h, double* before, double* after, int32_t* failed) {
+  return guard(h, [&]() -> int32_t {
+    if (!h) return ALTRO_ERR_INVALID_ARG;
+    const size_t B = h->d.batch;
+    if (h->wide) { const int rc_ = h->wide->polish_dual(before, after, failed); if (rc_) h->err = h->wide->err; return rc_; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->o.projected_newton) {
+      if (before) std::memset(before, 0, B * sizeof(double));
+      if (after) std::memset(after, 0, B * sizeof(double));
+      if (failed) std::memset(failed, 0, B * sizeof(int32_t));
+      return ALTRO_OK;
+    }
+    if (before) HIPCHK(h, hipMemcpy(before, h->pn_dres0, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (after) HIPCHK(h, hipMemcpy(after, h->pn_dres, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (failed) HIPCHK(h, hipMemcpy(failed, h->pn_dfail, B * sizeof(int), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   });
 }

@@ -42,9 +42,15 @@ struct PnParams {
   double *cost, *cmax;
   int *pn_ran, *pn_failed;
   double* pn_res;
+  // multiplier projection (the dual half of the polish): AL duals in, stationarity residuals out
+  const double *Lb, *Lc;   // [Bp][N+1][2][nbp], [Bp][N+1][16]
+  const int* bslot;        // [16]
+  int nbp;
+  int* pn_dfail;           // [Bp]
+  double *pn_dres0, *pn_dres;   // [Bp] ||g + D' lam||_2 with the AL duals / with the projected multipliers
   // workspace, per instance
   double *E, *dv, *Ld, *Lo, *vec;  // E [N][bm][16]; dv [N][bm]; Ld, Lo [N][bm][bm]; vec [6][N][bm] (lam, res, cor, Sv, dtrial, spare)
-  double* tz;                      // [N][16]
+  double* tz;                      // [3][N][16]: t of apply_S; the cost gradient g; g + D' lam
   int *nb, *nst, *rinfo;           // [N], [N], [N][bm] (row code: see pn_row)
   altro_opts o;
 };
@@ -57,7 +63,8 @@ __device__ __forceinline__ double wave_max(double v) {
 struct Pn {
   const PnParams& P;
   int inst, tid, N, n, m, nz, bm;
-  double *E, *dv, *Ld, *Lo, *lam, *res, *cor, *Sv, *dtr, *tz;
+  double *E, *dv, *Ld, *Lo, *lam, *res, *cor, *Sv, *dtr, *spare, *tz, *gz, *rz;
+  bool unit = false;   // the metric H = I of the multiplier projection (D D' instead of D H^-1 D')
   int *nb, *nst, *rinfo;
   double* Lc;  // LDS: current block [bm][bm+1]
   double* Lp;  // LDS: second block
@@ -74,7 +81,10 @@ struct Pn {
     Lo = P.Lo + i * N * bm * bm;
     double* v = P.vec + i * 6 * N * bm;
     lam = v; res = v + (size_t)N * bm; cor = v + 2 * (size_t)N * bm; Sv = v + 3 * (size_t)N * bm; dtr = v + 4 * (size_t)N * bm;
-    tz = P.tz + i * N * LW;
+    spare = v + 5 * (size_t)N * bm;
+    tz = P.tz + i * 3 * N * LW;
+    gz = tz + (size_t)N * LW;
+    rz = tz + 2 * (size_t)N * LW;
     nb = P.nb + i * N; nst = P.nst + i * N; rinfo = P.rinfo + i * N * bm;
     Lc = lds;
     Lp = lds + BMAX * (BMAX + 1);
@@ -88,6 +98,7 @@ struct Pn {
     return P.Z + ((size_t)inst * (2 * (size_t)N + 1) + (size_t)plane * N + k) * LW;
   }
   __device__ __forceinline__ double hinv(int k, int j) const {
+    if (unit) return 1.0;
     const double h = (k < N - 1) ? P.wd[j] : (j < n ? P.wf[j] : 0.0);
     return 1.0 / (h + P.o.rho_primal);
   }
@@ -235,6 +246,11 @@ struct Pn {
 
   // y = S v; also leaves t_k = H_k^-1 (E_k' v_k - [defect part of v_{k-1}]_x) in tz
   __device__ void apply_S(const double* v, double* y) {
+    apply_Dt(v);
+    apply_D(tz, y);
+  }
+  // tz = H^-1 D' v
+  __device__ void apply_Dt(const double* v) {
     for (int e = tid; e < N * LW; e += 64) {
       const int k = e / LW, j = e % LW;
       double acc = 0.0;
@@ -247,17 +263,102 @@ struct Pn {
       tz[e] = acc;
     }
     __syncthreads();
+  }
+  // y = D t   (t: [N][16])
+  __device__ void apply_D(const double* t, double* y) {
     for (int e = tid; e < N * bm; e += 64) {
       const int k = e / bm, r = e % bm;
       if (r >= nb[k]) continue;
       const double* Ek = E + (size_t)k * bm * LW;
       double acc = 0.0;
-      for (int j = 0; j < nz; ++j) acc += Ek[(size_t)r * LW + j] * tz[(size_t)k * LW + j];
+      for (int j = 0; j < nz; ++j) acc += Ek[(size_t)r * LW + j] * t[(size_t)k * LW + j];
       const int off = nb[k] - n;
-      if (k < N - 1 && r >= off) acc -= tz[(size_t)(k + 1) * LW + (r - off)];
+      if (k < N - 1 && r >= off) acc -= t[(size_t)(k + 1) * LW + (r - off)];
       y[e] = acc;
     }
     __syncthreads();
+  }
+
+  __device__ __forceinline__ double wave_sum(double v) const {
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+  }
+
+  // multiplier_projection! of Altro.jl's ProjectedNewtonSolver (oracle multiplier_projection): lam <- lam - (D D')^-1 D (g + D' lam)
+  // at the polished trajectory, with the stationarity residual before and after.  The multipliers are not written back.
+  __device__ void multiplier_projection(int cur) {
+    linearise(cur);
+    unit = true;
+    for (int e = tid; e < N * bm; e += 64) lam[e] = 0.0;
+    for (int e = tid; e < N * LW; e += 64) {   // g_k = H_k (z_k - zref_k)
+      const int k = e / LW, j = e % LW;
+      const bool live = j < n || (j < nz && k < N - 1);
+      const double h = (k < N - 1) ? P.wd[j] : (j < n ? P.wf[j] : 0.0);
+      gz[e] = live ? h * (zrow(cur, k)[j] - P.Zref[((size_t)inst * P.Nt + (size_t)(P.kref + k)) * LW + j]) : 0.0;
+    }
+    __syncthreads();
+    for (int k = tid; k < N; k += 64) {        // lam0: the AL duals of the active box / linear rows
+      const int base = (k == 0) ? n : 0;
+      for (int q = 0; q < nst[k]; ++q) {
+        const int code = rinfo[(size_t)k * bm + q];
+        double l0 = 0.0;
+        if (code < 32) {
+          const int sl = P.bslot[code & 15];
+          if (sl >= 0) l0 = P.Lb[(((size_t)inst * (N + 1) + k) * 2 + (code >> 4)) * P.nbp + sl];
+        } else {
+          const int lane = code - 64;
+          if (P.cmeta[((size_t)k * LW + lane) * 4] != 3) l0 = P.Lc[((size_t)inst * (N + 1) + k) * LW + lane];
+        }
+        lam[(size_t)k * bm + base + q] = l0;
+      }
+    }
+    __syncthreads();
+    apply_Dt(lam);
+    double r0 = 0.0;
+    for (int e = tid; e < N * LW; e += 64) {
+      const double v = gz[e] + tz[e];
+      rz[e] = v;
+      r0 += v * v;
+    }
+    __syncthreads();
+    r0 = wave_sum(r0);
+    const bool ok = factor();
+    if (ok) {
+      apply_D(rz, dtr);                        // rhs = D (g + D' lam0)
+      chol_solve(dtr, cor);
+      for (int it = 0; it < 25; ++it) {        // reg_solve against D D'
+        apply_S(cor, Sv);
+        double rn = 0.0;
+        for (int e = tid; e < N * bm; e += 64) {
+          const double v = ((e % bm) < nb[e / bm]) ? dtr[e] - Sv[e] : 0.0;
+          res[e] = v;
+          rn = fmax(rn, fabs(v));
+        }
+        __syncthreads();
+        rn = wave_max(rn);
+        if (rn < 1e-8) break;
+        chol_solve(res, spare);
+        for (int e = tid; e < N * bm; e += 64)
+          if ((e % bm) < nb[e / bm]) cor[e] += spare[e];
+        __syncthreads();
+      }
+      for (int e = tid; e < N * bm; e += 64)
+        if ((e % bm) < nb[e / bm]) lam[e] -= cor[e];
+      __syncthreads();
+    }
+    apply_Dt(lam);
+    double r1 = 0.0;
+    for (int e = tid; e < N * LW; e += 64) {
+      const double v = gz[e] + tz[e];
+      r1 += v * v;
+    }
+    r1 = wave_sum(r1);
+    unit = false;
+    if (tid == 0) {
+      P.pn_dfail[inst] = ok ? 0 : 1;
+      P.pn_dres0[inst] = sqrt(r0);
+      P.pn_dres[inst] = sqrt(r1);
+    }
   }
 
   // S + rho_chol I = L L'.  Returns false if a pivot is not positive.
@@ -381,7 +482,7 @@ struct Pn {
     const int cur = P.cur[inst];
     const bool need = (P.status[inst] <= ALTRO_SOLVE_SUCCEEDED) && (P.cmax[inst] > o.constraint_tolerance);
     if (!need) {
-      if (tid == 0) { P.pn_ran[inst] = 0; P.pn_failed[inst] = 0; P.pn_res[inst] = 0.0; }
+      if (tid == 0) { P.pn_ran[inst] = 0; P.pn_failed[inst] = 0; P.pn_res[inst] = 0.0; P.pn_dfail[inst] = 0; P.pn_dres0[inst] = 0.0; P.pn_dres[inst] = 0.0; }
       return;
     }
     double viol = linearise(cur);
@@ -432,6 +533,9 @@ struct Pn {
         if (rate < o.r_threshold) break;
       }
     }
+    if (!failed) multiplier_projection(cur);
+    else if (tid == 0) { P.pn_dfail[inst] = 1; P.pn_dres0[inst] = 0.0; P.pn_dres[inst] = 0.0; }
+    __syncthreads();
     // objective (no AL terms) and violation of the problem's constraints at the polished trajectory
     double J = 0.0, cm = 0.0;
     for (int k = tid; k < N; k += 64) {

@@ -5,12 +5,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/altro_batch.h"
 #include "launch_ring.h"
 #include "solve_wide.h"
+#include "pn_wide.h"
 
 namespace altro_wide {
 
@@ -60,6 +62,12 @@ struct WideBackend {
   int coop_mode = -1, static_mask = 7;  // altro_debug_set "wide_coop", "wide_static_mask" (before create)
   int compact_np_max = 48;  // wide_compact: the LDS carve-up with Qux and K inside W, for padded state dimensions up to this
   bool debug_keep_gains = false;  // altro_debug_set "keep_gains" (-DALTRO_DEBUG builds only): stale gains are kept (exists to show that the tests notice them)
+  // projected-Newton polish (pn_wide.h): per-instance results, and the workspace slots allocated by the first solve that asks
+  int *pn_ran = nullptr, *pn_failed = nullptr, *pn_dfail = nullptr;
+  double *pn_res = nullptr, *pn_dres0 = nullptr, *pn_dres = nullptr;
+  double *pnE = nullptr, *pndv = nullptr, *pnLd = nullptr, *pnLo = nullptr, *pnvec = nullptr, *pntz = nullptr, *pnblk = nullptr;
+  int *pnnb = nullptr, *pnnst = nullptr, *pnrinfo = nullptr;
+  int pn_bm = 0, pn_slots = 0;
   bool gains_valid = false;   // nothing the stored gains depend on (model, cost, constraints, options) has changed since the last launch
   double *Xsave = nullptr, *Usave = nullptr;  // Z0 of benchmark_solve
   std::vector<hipEvent_t> bench_ev;
@@ -152,7 +160,8 @@ struct WideBackend {
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
-                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, n_gs, fac, bwst};
+                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, n_gs, fac, bwst,
+                    pn_ran, pn_failed, pn_dfail, pn_res, pn_dres0, pn_dres, pnE, pndv, pnLd, pnLo, pnvec, pntz, pnblk, pnnb, pnnst, pnrinfo};
     for (void* p : ptrs)
       if (p) hipFree(p);
     ring.destroy();
@@ -433,7 +442,81 @@ struct WideBackend {
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
     p.compact = compact();
     p.o = o;
+    if (o.projected_newton) {  // solve!(::ALTROSolver): the AL stage only has to reach the polish's tolerance
+      if (o.projected_newton_tolerance >= 0) p.o.constraint_tolerance = o.projected_newton_tolerance;
+      else { p.o.constraint_tolerance = 0.0; p.o.kickout_max_penalty = 1; }
+    }
     return p;
+  }
+
+  // solve!(::ProjectedNewtonSolver) after the AL kernel of a plain solve: every check and allocation BEFORE the launch takes
+  // its slot of the timing ring
+  int polish_prepare() {
+    const size_t B = d.batch, N = d.N, z = nz();
+    if (!pn_ran) {
+      int rc;
+      if ((rc = dalloc(&pn_ran, B)) || (rc = dalloc(&pn_failed, B)) || (rc = dalloc(&pn_dfail, B)) || (rc = dalloc(&pn_res, B)) ||
+          (rc = dalloc(&pn_dres0, B)) || (rc = dalloc(&pn_dres, B))) return rc;
+    }
+    std::vector<double> lo(z), hi(z);
+    WCHK(hipMemcpy(lo.data(), zmin, z * sizeof(double), hipMemcpyDeviceToHost));
+    WCHK(hipMemcpy(hi.data(), zmax, z * sizeof(double), hipMemcpyDeviceToHost));
+    int sides = 0;
+    if (box_k1 >= box_k0)
+      for (size_t j = 0; j < z; ++j) sides += (lo[j] > -1e300 ? 1 : 0) + (hi[j] < 1e300 ? 1 : 0);
+    const int bm = 2 * d.n + sides + Pn;
+    const int slots = (int)(B < 64 ? B : 64);
+    if (bm != pn_bm || slots != pn_slots || !pnE) {
+      void** ws[] = {(void**)&pnE, (void**)&pndv, (void**)&pnLd, (void**)&pnLo, (void**)&pnvec, (void**)&pntz, (void**)&pnblk,
+                     (void**)&pnnb, (void**)&pnnst, (void**)&pnrinfo};
+      for (void** q : ws) if (*q) { WCHK(hipFree(*q)); *q = nullptr; }
+      const size_t S = slots, b = bm;
+      WCHK(hipMalloc(&pnE, S * N * b * z * sizeof(double)));
+      WCHK(hipMalloc(&pndv, S * N * b * sizeof(double)));
+      WCHK(hipMalloc(&pnLd, S * N * b * b * sizeof(double)));
+      WCHK(hipMalloc(&pnLo, S * N * b * b * sizeof(double)));
+      WCHK(hipMalloc(&pnvec, S * 6 * N * b * sizeof(double)));
+      WCHK(hipMalloc(&pntz, S * 3 * N * z * sizeof(double)));
+      WCHK(hipMalloc(&pnblk, S * (2 * b * (b + 1) + 4 * b) * sizeof(double)));
+      WCHK(hipMalloc(&pnnb, S * N * sizeof(int)));
+      WCHK(hipMalloc(&pnnst, S * N * sizeof(int)));
+      WCHK(hipMalloc(&pnrinfo, S * N * b * sizeof(int)));
+      pn_bm = bm;
+      pn_slots = slots;
+    }
+    return ALTRO_OK;
+  }
+  int polish_launch() {
+    altro_pnw::WParams w{};
+    w.P = params();
+    w.P.o = o;   // the caller's tolerances (params() carries the AL stage's)
+    w.bm = pn_bm; w.nslots = pn_slots;
+    w.pn_ran = pn_ran; w.pn_failed = pn_failed; w.pn_dfail = pn_dfail; w.pn_res = pn_res; w.pn_dres0 = pn_dres0; w.pn_dres = pn_dres;
+    w.E = pnE; w.dv = pndv; w.Ld = pnLd; w.Lo = pnLo; w.vec = pnvec; w.tz = pntz; w.blk = pnblk;
+    w.nb = pnnb; w.nst = pnnst; w.rinfo = pnrinfo;
+    hipLaunchKernelGGL(altro_pnw::pnw_kernel, dim3(pn_slots), dim3(64), 0, stream, w, o.constraint_tolerance);
+    WCHK(hipGetLastError());
+    return ALTRO_OK;
+  }
+  int polish_stats(int32_t* ran, int32_t* failed, double* residual) {
+    WCHK(hipSetDevice(device));
+    WCHK(hipStreamSynchronize(stream));
+    const size_t B = d.batch;
+    const bool have = o.projected_newton && pn_ran;
+    if (ran) { if (have) WCHK(hipMemcpy(ran, pn_ran, B * sizeof(int), hipMemcpyDeviceToHost)); else std::memset(ran, 0, B * sizeof(int32_t)); }
+    if (failed) { if (have) WCHK(hipMemcpy(failed, pn_failed, B * sizeof(int), hipMemcpyDeviceToHost)); else std::memset(failed, 0, B * sizeof(int32_t)); }
+    if (residual) { if (have) WCHK(hipMemcpy(residual, pn_res, B * sizeof(double), hipMemcpyDeviceToHost)); else std::memset(residual, 0, B * sizeof(double)); }
+    return ALTRO_OK;
+  }
+  int polish_dual(double* before, double* after, int32_t* failed) {
+    WCHK(hipSetDevice(device));
+    WCHK(hipStreamSynchronize(stream));
+    const size_t B = d.batch;
+    const bool have = o.projected_newton && pn_ran;
+    if (before) { if (have) WCHK(hipMemcpy(before, pn_dres0, B * sizeof(double), hipMemcpyDeviceToHost)); else std::memset(before, 0, B * sizeof(double)); }
+    if (after) { if (have) WCHK(hipMemcpy(after, pn_dres, B * sizeof(double), hipMemcpyDeviceToHost)); else std::memset(after, 0, B * sizeof(double)); }
+    if (failed) { if (have) WCHK(hipMemcpy(failed, pn_dfail, B * sizeof(int), hipMemcpyDeviceToHost)); else std::memset(failed, 0, B * sizeof(int32_t)); }
+    return ALTRO_OK;
   }
 
   int compact() const {  // only for one-wave blocks: the helper waves of a cooperative block read W while wave 0 writes Qux
@@ -474,14 +557,21 @@ struct WideBackend {
     if (mpc && ltv && dyn_step_stride == 0)
       WFAIL(ALTRO_ERR_UNSUPPORTED, "the device MPC loop over per-knot dynamics needs their table for every step: altro_mpc_set_dynamics_track");
     if (!dyn_covers(last_kref)) WFAIL(ALTRO_ERR_STATE, "the dynamics track ends before the last step's window");
+    if (o.projected_newton && mpc)
+      WFAIL(ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
+                                   "(every MPC script of the reference sets projected_newton = false)");
+    if (o.projected_newton && (rc = polish_prepare())) return rc;
     hipEvent_t h0, h1;
     WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
     WCHK(hipEventRecord(h0, stream));
     hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
-    WCHK(hipGetLastError());
+    rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
+    if (rc) err = "launch of the solve kernel failed";
+    if (!rc && o.projected_newton) rc = polish_launch();
     gains_valid = true;  // (until a setter changes something the stored gains depend on)
-    WCHK(hipEventRecord(h1, stream));
+    WCHK(hipEventRecord(h1, stream));   // (every slot of the ring handed out has both events)
+    if (rc) return rc;
     WCHK(hipEventRecord(ev1, stream));
     timed = true;
     if (mpc) kref = first_step + nsteps;

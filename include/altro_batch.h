@@ -133,8 +133,10 @@ typedef struct altro_opts {
    * solve!(::ProjectedNewtonSolver) if the violation is still above constraint_tolerance; ALTRO, IROS 2019, Algorithm 4).
    * altro_default_opts() gives 0: Altro.jl's own default is true, but every script of the reference on this path sets
    * projected_newton = false (eleven occurrences), and the ccall shim passes the Julia-side value explicitly.  1: plain
-   * solves (altro_batch_solve) of the 16-lane backend run csrc/pn_polish.h after the AL kernel; the device-resident MPC
-   * loop and the one-wave-per-instance backend refuse it.  PARITY UNPINNED: the reference stores no polished trajectory. */
+   * solves (altro_batch_solve) run the polish after the AL kernel -- csrc/pn_polish.h on the 16-lane backend, csrc/pn_wide.h
+   * on the one-wave-per-instance backend (any n <= 64, m <= 32, per-knot dynamics) -- primal projection first, then
+   * Altro's multiplier projection (altro_batch_get_polish_dual_residuals); the device-resident MPC loop refuses it.
+   * PARITY UNPINNED: the reference stores no polished trajectory. */
   int32_t projected_newton;
   double projected_newton_tolerance;   /* 1e-3 */
   double active_set_tolerance_pn;      /* 1e-3: inequality rows with c >= -tol join the polish's active set */
@@ -284,6 +286,14 @@ int32_t altro_batch_get_reuse_counter(altro_handle* h, int64_t* reused);
  * positive definite), residual (final max |d| over the active rows, the initial condition and the dynamics defects).
  * All zero when altro_opts.projected_newton = 0. */
 int32_t altro_batch_get_polish_stats(altro_handle* h, int32_t* ran, int32_t* failed, double* residual);
+/* The dual half of the polish (multiplier_projection! of Altro.jl's ProjectedNewtonSolver; ALTRO, IROS 2019, IV-B): at
+ * the polished trajectory the multipliers of the polish's active rows D (initial condition, active constraint rows,
+ * dynamics) are projected, lam <- lam - (D D')^-1 D (g + D' lam), g the gradient of the cost.  Per instance (arrays of
+ * `batch`; any pointer may be NULL): the stationarity residual ||g + D' lam||_2 `before` (AL duals on the active box /
+ * linear rows, zero elsewhere) and `after` the projection, and whether a block of D D' was not positive definite.  The
+ * projected multipliers stay inside the polish, as Altro's do; the AL duals (altro_batch_get_duals) are untouched.
+ * All zero when the polish did not run. */
+int32_t altro_batch_get_polish_dual_residuals(altro_handle* h, double* before, double* after, int32_t* failed);
 /* Diagnostic (16-lane kernels): 16 int64 per wave (4 instances) of the last solve launch.  [0] s_memtime ticks in
  * total; [7] backward passes the wave ran in the lone-row form (one instance over the four DPP rows).  The
  * -DALTRO_PHASE_STAMPS build also fills ticks per phase -- [1] four-row backward passes, [2] closed-loop rollouts,

@@ -1169,6 +1169,103 @@ static void pn_chol_solve(const orc_solver* s, const pn_ws* w, const double* b, 
   }
 }
 
+/* multiplier_projection! of Altro.jl's ProjectedNewtonSolver [PKG] (ALTRO, IROS 2019, section IV-B): the least-squares
+ * multipliers of the polish's active rows D (initial condition, active stage rows, dynamics defects) at the polished
+ * trajectory,
+ *     lam <- lam - (D D')^-1 D (g + D' lam),        g = gradient of the cost (no AL terms),
+ * and the stationarity residual ||g + D' lam||_2 before and after.  D D' has the block structure of S with the metric
+ * H = I, so the same block factorisation serves (pn_factor with hinv = 1; reg_solve refinement against D D' itself).
+ * lam starts from the AL duals of the active box / linear rows and from zero for cones (the polish sees a cone as the
+ * one row ||v|| - t), the initial condition and the dynamics; the projected multipliers do not depend on that start
+ * when D D' is regular, only the "before" residual does.  They are NOT written back into the AL duals (Altro's own
+ * polish keeps its multiplier vector to itself; PARITY UNPINNED as for the primal half): the two residuals are the
+ * output, stats.pn_dual_residual0 / pn_dual_residual.  Called with w linearised at the final (X, U). */
+static void pn_Dt(const orc_solver* s, const pn_ws* w, const double* v, double* tz) {   /* tz = D' v  (metric-free) */
+  int n = s->n, N = s->N, nz = s->nz, bm = w->bmax;
+  for (int k = 0; k < N; ++k) {
+    const double* E = w->E + (size_t)k * bm * nz;
+    double* t = tz + (size_t)k * nz;
+    for (int j = 0; j < nz; ++j) {
+      double acc = 0;
+      for (int r = 0; r < w->nb[k]; ++r) acc += E[(size_t)r * nz + j] * v[(size_t)k * bm + r];
+      t[j] = acc;
+    }
+    if (k > 0) {
+      int off = w->nb[k - 1] - n;
+      for (int i = 0; i < n; ++i) t[i] -= v[(size_t)(k - 1) * bm + off + i];
+    }
+  }
+}
+
+static void pn_D(const orc_solver* s, const pn_ws* w, const double* tz, double* y) {   /* y = D tz */
+  int n = s->n, N = s->N, nz = s->nz, bm = w->bmax;
+  for (int k = 0; k < N; ++k) {
+    const double* E = w->E + (size_t)k * bm * nz;
+    for (int r = 0; r < w->nb[k]; ++r) {
+      double acc = 0;
+      for (int j = 0; j < nz; ++j) acc += E[(size_t)r * nz + j] * tz[(size_t)k * nz + j];
+      y[(size_t)k * bm + r] = acc;
+    }
+    if (k < N - 1) {
+      int off = w->nb[k] - n;
+      for (int i = 0; i < n; ++i) y[(size_t)k * bm + off + i] -= tz[(size_t)(k + 1) * nz + i];
+    }
+  }
+}
+
+static int multiplier_projection(orc_solver* s, pn_ws* w, double* res0_out, double* res_out) {
+  int n = s->n, m = s->m, N = s->N, nz = s->nz, bm = w->bmax;
+  double *lam = dalloc((size_t)N * bm), *rhs = dalloc((size_t)N * bm), *del = dalloc((size_t)N * bm), *cor = dalloc((size_t)N * bm);
+  double *Av = dalloc((size_t)N * bm), *g = dalloc((size_t)N * nz), *tz = dalloc((size_t)N * nz), *r0 = dalloc((size_t)N * nz);
+  for (size_t i = 0; i < (size_t)N * nz; ++i) w->hinv[i] = 1.0;          /* the metric of D D' */
+  /* cost gradient (diagonal tracking cost): g_k = H_k (z_k - zref_k) */
+  for (int k = 0; k < N; ++k) {
+    for (int i = 0; i < n; ++i)
+      g[(size_t)k * nz + i] = ((k < N - 1) ? s->dt * s->Qd[i] : s->Qfd[i]) * (s->X[(size_t)k * n + i] - s->Xref[(size_t)k * n + i]);
+    for (int i = 0; i < m; ++i)
+      g[(size_t)k * nz + n + i] = (k < N - 1) ? s->dt * s->Rd[i] * (s->U[(size_t)k * m + i] - s->Uref[(size_t)k * m + i]) : 0.0;
+  }
+  /* lam0: AL duals of the active box / linear rows */
+  for (int k = 0; k < N; ++k) {
+    int base = (k == 0) ? n : 0;
+    for (int q = 0; q < w->nst[k]; ++q) {
+      const con_t* c = &s->con[w->rcon[(size_t)k * bm + q]];
+      int r = w->rrow[(size_t)k * bm + q];
+      lam[(size_t)k * bm + base + q] = (c->kind == ORC_SOC) ? 0.0 : c->lam[(size_t)(k - c->k0) * c->p + r];
+    }
+  }
+  pn_Dt(s, w, lam, tz);
+  double res0 = 0;
+  for (size_t i = 0; i < (size_t)N * nz; ++i) { r0[i] = g[i] + tz[i]; res0 += r0[i] * r0[i]; }
+  int rc = pn_factor(s, w);
+  if (!rc) {
+    pn_D(s, w, r0, rhs);
+    pn_chol_solve(s, w, rhs, del);
+    for (int it = 0; it < 25; ++it) {                                      /* reg_solve against D D' */
+      pn_Dt(s, w, del, tz);
+      pn_D(s, w, tz, Av);
+      double rn = 0;
+      for (int k = 0; k < N; ++k)
+        for (int r = 0; r < w->nb[k]; ++r) {
+          double e = rhs[(size_t)k * bm + r] - Av[(size_t)k * bm + r];
+          Av[(size_t)k * bm + r] = e;
+          if (fabs(e) > rn) rn = fabs(e);
+        }
+      if (rn < 1e-8) break;
+      pn_chol_solve(s, w, Av, cor);
+      for (int k = 0; k < N; ++k) for (int r = 0; r < w->nb[k]; ++r) del[(size_t)k * bm + r] += cor[(size_t)k * bm + r];
+    }
+    for (int k = 0; k < N; ++k) for (int r = 0; r < w->nb[k]; ++r) lam[(size_t)k * bm + r] -= del[(size_t)k * bm + r];
+  }
+  pn_Dt(s, w, lam, tz);
+  double res = 0;
+  for (size_t i = 0; i < (size_t)N * nz; ++i) { double e = g[i] + tz[i]; res += e * e; }
+  *res0_out = sqrt(res0);
+  *res_out = sqrt(res);
+  free(lam); free(rhs); free(del); free(cor); free(Av); free(g); free(tz); free(r0);
+  return rc;
+}
+
 static int projected_newton(orc_solver* s, double* viol_out) {
   const orc_opts* o = &s->opts;
   int n = s->n, m = s->m, N = s->N, nz = s->nz;
@@ -1235,6 +1332,13 @@ static int projected_newton(orc_solver* s, double* viol_out) {
     }
   }
   *viol_out = viol;
+  if (!rc) {   /* the dual half: multipliers of the active rows at the polished trajectory */
+    pn_linearise(s, &w, s->X, s->U);
+    double r0 = 0, r1 = 0;
+    s->stats.pn_dual_failed = multiplier_projection(s, &w, &r0, &r1);
+    s->stats.pn_dual_residual0 = r0;
+    s->stats.pn_dual_residual = r1;
+  }
   free(w.nb); free(w.nst); free(w.rcon); free(w.rrow); free(w.E); free(w.dv); free(w.Ld); free(w.Lo); free(w.hinv);
   free(lam); free(res); free(cor); free(Sv); free(tz); free(dz); free(dtrial);
   return rc;

@@ -113,6 +113,9 @@ typedef struct {
   /* projected-Newton polish */
   int pn_ran, pn_failed;     /* the polish ran (AL ended above constraint_tolerance); a block of S was not positive definite */
   double pn_residual;        /* its final ||d||_inf (active rows, initial condition, dynamics defects) */
+  /* multiplier projection after the primal polish: ||g + D' lam||_2 with the AL duals / with the projected multipliers */
+  int pn_dual_failed;
+  double pn_dual_residual0, pn_dual_residual;
 } orc_stats;
 
 typedef struct orc_solver orc_solver;

@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("grad", C.c_double * TRACE_MAX), ("alpha", C.c_double * TRACE_MAX),
                 ("cmax_it", C.c_double * TRACE_MAX),
                 ("c_max_outer", C.c_double * 64), ("penalty_max_outer", C.c_double * 64),
-                ("pn_ran", C.c_int), ("pn_failed", C.c_int), ("pn_residual", C.c_double)]
+                ("pn_ran", C.c_int), ("pn_failed", C.c_int), ("pn_residual", C.c_double),
+                ("pn_dual_failed", C.c_int), ("pn_dual_residual0", C.c_double), ("pn_dual_residual", C.c_double)]
 
 
 def build(force=False):

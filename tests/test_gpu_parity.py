@@ -1677,6 +1677,7 @@ def test_projected_newton_polish_matches_oracle(oracle):
     altro.solve(sv)
     st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
     ran, failed, res = altro.polish_stats(sv)
+    d0, d1, dfail = altro.polish_dual_residuals(sv)
     assert ran.sum() >= 3 and not failed.any()
     for b in range(B):
         o = make_oracle(oracle, pb, b, opts=opts)
@@ -1687,6 +1688,11 @@ def test_projected_newton_polish_matches_oracle(oracle):
         assert rel_err(X[b], o.states()) <= RTOL and rel_err(U[b], o.controls()) <= RTOL
         if ran[b]:
             assert np.abs(X[b, :-1] @ pb.A[b].T + U[b] @ pb.Bm[b].T - X[b, 1:]).max() < 1e-8 and np.abs(U[b]).max() <= pb.u_bnd + 1e-8
+        # the dual half (Altro's multiplier projection): stationarity residual with the AL duals and with the projected multipliers
+        assert int(dfail[b]) == so.pn_dual_failed == 0
+        assert abs(d0[b] - so.pn_dual_residual0) <= 1e-6 * max(1.0, so.pn_dual_residual0) and abs(d1[b] - so.pn_dual_residual) <= 1e-6 * max(1.0, so.pn_dual_residual0)
+        if ran[b]:
+            assert d1[b] < 1e-5 * d0[b]       # a polished optimum: the KKT conditions hold with the projected multipliers
     # the grasp problem: AL stage to a loose 1e-2, polish to 1e-6
     gp = P.gen_grasp_problem(N=31, tf=3.0)
     gopts = dict(cost_tolerance_intermediate=1e-5, penalty_initial=1.0, penalty_scaling=10.0, constraint_tolerance=1e-6,
@@ -1697,6 +1703,7 @@ def test_projected_newton_polish_matches_oracle(oracle):
     altro.solve(sg)
     st, X, U = altro.stats(sg), altro.states(sg), altro.controls(sg)
     ran, failed, res = altro.polish_stats(sg)
+    d0, d1, dfail = altro.polish_dual_residuals(sg)
     assert ran.all() and not failed.any() and res.max() < 1e-6
     for b in range(3):
         o = rocket_oracle(oracle, gp, x0[b], gopts)
@@ -1704,13 +1711,83 @@ def test_projected_newton_polish_matches_oracle(oracle):
         assert so.pn_ran == 1 and int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations
         assert st.c_max[b] < 1e-6 and abs(st.cost[b] - so.cost) <= 1e-5 * max(1.0, abs(so.cost))
         assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-5
-    # the device-resident MPC loop and the one-wave-per-instance backend refuse the option
+        assert int(dfail[b]) == so.pn_dual_failed
+        assert abs(d0[b] - so.pn_dual_residual0) <= 1e-4 * max(1.0, so.pn_dual_residual0) and abs(d1[b] - so.pn_dual_residual) <= 1e-4 * max(1.0, so.pn_dual_residual0)
+    # the device-resident MPC loop refuses the option
     with pytest.raises(altro.AltroError):
         mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(**opts))
         mp.initial_solve()
         mp.step(0)
-    with pytest.raises(altro.AltroError):
-        altro.ALTROSolver(altro.mpc.gen_tracking_problem(altro.problems.gen_random_linear_batch(2, n=20, m=4, N=11, steps=1)), altro.SolverOptions(**opts))
+
+
+def test_projected_newton_polish_on_the_one_wave_per_instance_backend(oracle, monkeypatch):
+    """SURVEY 8 f4 on the second backend (csrc/pn_wide.h; parity with Altro.jl unpinned as above): projected_newton = 1 on
+    sizes outside the 16-lane set -- (a) box-constrained LQ at (20, 4) with saturating controls, (b) the quadruped tick
+    (n = m = 12, per-knot dynamics, friction rows + f_z box), (c) the grasp problem forced onto this backend (cones,
+    per-knot equalities and inequalities, goal) -- against the oracle's polish: same AL stage, same decision to polish,
+    polished trajectories, objective and both residuals of the multiplier projection."""
+    B = 4
+    pb = altro.problems.gen_random_linear_batch(B, n=20, m=4, N=21, steps=1, seed=85)
+    prob = altro.mpc.gen_tracking_problem(pb)
+    prob.x0 = prob.x0 + np.array([20.0, 15.0, 0.1, 25.0])[:, None]
+    opts = dict(REF_OPTS, constraint_tolerance=1e-8, projected_newton=1)
+    sv = altro.ALTROSolver(prob, altro.SolverOptions(**opts))
+    assert altro.wave_cycles(sv).size == 0        # wide path
+    altro.solve(sv)
+    st, X, U = altro.stats(sv), altro.states(sv), altro.controls(sv)
+    ran, failed, res = altro.polish_stats(sv)
+    d0, d1, dfail = altro.polish_dual_residuals(sv)
+    assert ran.sum() >= 2 and not failed.any()
+    for b in range(B):
+        o = make_oracle(oracle, pb, b, opts=opts)
+        o.set_initial_state(prob.x0[b])
+        so = o.solve()
+        assert int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations and int(ran[b]) == so.pn_ran
+        assert abs(st.cost[b] - so.cost) <= RTOL * max(1.0, abs(so.cost)) and st.c_max[b] < 1e-8
+        assert rel_err(X[b], o.states()) <= RTOL and rel_err(U[b], o.controls()) <= RTOL
+        assert int(dfail[b]) == so.pn_dual_failed == 0
+        assert abs(d0[b] - so.pn_dual_residual0) <= 1e-6 * max(1.0, so.pn_dual_residual0) and abs(d1[b] - so.pn_dual_residual) <= 1e-6 * max(1.0, so.pn_dual_residual0)
+        if ran[b]:
+            assert np.abs(X[b, :-1] @ pb.A[b].T + U[b] @ pb.Bm[b].T - X[b, 1:]).max() < 1e-8 and np.abs(U[b]).max() <= pb.u_bnd + 1e-8
+            assert d1[b] < 1e-5 * d0[b]
+    # (b) one quadruped tick: per-knot dynamics, linearised friction pyramids, f_z box
+    N = 10
+    qb = P.gen_quadruped_batch(3, N=N, steps=1, seed=19)
+    qopts = dict(P.QUADRUPED_OPTS, constraint_tolerance=1e-7, projected_newton=1, projected_newton_tolerance=1e-2)
+    sq = altro.ALTROSolver(quadruped_gpu_problem(altro, qb.qp, qb.x0, qb.A[:, :N - 1], qb.Bm[:, :N - 1], qb.d[:, :N - 1]), altro.SolverOptions(**qopts))
+    altro.solve(sq)
+    st, X, U = altro.stats(sq), altro.states(sq), altro.controls(sq)
+    ran, failed, res = altro.polish_stats(sq)
+    d0, d1, dfail = altro.polish_dual_residuals(sq)
+    assert not failed.any()
+    for b in range(3):
+        o = quadruped_oracle(oracle, qb.qp, qb.x0[b], qb.A[b, :N - 1], qb.Bm[b, :N - 1], qb.d[b, :N - 1], qopts)
+        so = o.solve()
+        assert int(st.status[b]) == so.status and int(st.iterations[b]) == so.iterations and int(ran[b]) == so.pn_ran
+        assert abs(st.cost[b] - so.cost) <= 1e-5 * max(1.0, abs(so.cost)) and abs(st.c_max[b] - so.c_max) <= 1e-7
+        assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-5
+        assert abs(d0[b] - so.pn_dual_residual0) <= 1e-4 * max(1.0, so.pn_dual_residual0) and abs(d1[b] - so.pn_dual_residual) <= 1e-4 * max(1.0, so.pn_dual_residual0)
+    assert ran.sum() >= 1
+    # (c) the grasp problem on this backend
+    monkeypatch.setenv("ALTRO_FORCE_WIDE", "1")
+    rng = np.random.default_rng(3)
+    gp = P.gen_grasp_problem(N=31, tf=3.0)
+    gopts = dict(cost_tolerance_intermediate=1e-5, penalty_initial=1.0, penalty_scaling=10.0, constraint_tolerance=1e-6,
+                 projected_newton=1, projected_newton_tolerance=1e-2)
+    x0 = np.tile(gp.x0, (2, 1))
+    x0[1:, 1:3] += 0.1 * rng.standard_normal((1, 2))
+    sg = altro.ALTROSolver(rocket_gpu_problem(altro, gp, x0), altro.SolverOptions(**gopts))
+    assert altro.wave_cycles(sg).size == 0
+    altro.solve(sg)
+    st, X, U = altro.stats(sg), altro.states(sg), altro.controls(sg)
+    ran, failed, res = altro.polish_stats(sg)
+    assert ran.all() and not failed.any() and res.max() < 1e-6
+    for b in range(2):
+        o = rocket_oracle(oracle, gp, x0[b], gopts)
+        so = o.solve()
+        assert so.pn_ran == 1 and int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations
+        assert st.c_max[b] < 1e-6 and abs(st.cost[b] - so.cost) <= 1e-5 * max(1.0, abs(so.cost))
+        assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-5
 
 
 def test_initial_state_uploaded_before_per_knot_dynamics_survives_the_move_to_the_wide_kernel():

@@ -312,3 +312,50 @@ def test_projected_newton_polish_box_constrained_lq(oracle):
     assert np.abs(U).max() <= 3.0 + 1e-8
     assert np.abs(X - tight.states()).max() < 1e-7 and np.abs(U - tight.controls()).max() < 1e-7
     assert np.abs(X[:-1] @ pb.A[0].T + U @ pb.Bm[0].T - X[1:]).max() < 1e-8
+
+
+def test_multiplier_projection_after_the_polish(oracle):
+    """SURVEY 8 f4, second half: Altro's multiplier projection after the primal polish -- the least-squares multipliers of
+    the polish's active rows D (initial condition, active bounds, dynamics) at the polished trajectory,
+    lam = -(D D')^-1 D g, and the stationarity residual ||g + D' lam||_2 before (AL duals, zero elsewhere) and after.
+    Checked against a dense numpy restatement: the residual after is ||(I - D'(D D')^-1 D) g||, and at the (polished)
+    optimum of the box-constrained LQ problem it vanishes -- the KKT conditions hold with those multipliers."""
+    import altro_mpc_icra2021_amd as altro
+    from helpers import REF_OPTS, make_oracle
+    pb = altro.problems.gen_random_linear_batch(2, n=4, m=2, N=12, steps=1, seed=83)
+    x0 = pb.window(0)[0][0, 0] + 12.0
+    pol = make_oracle(oracle, pb, 0, opts=dict(REF_OPTS, constraint_tolerance=1e-9, projected_newton=1))
+    pol.set_initial_state(x0)
+    sp = pol.solve()
+    assert sp.status == 1 and sp.pn_ran == 1 and sp.pn_failed == 0 and sp.pn_dual_failed == 0
+    X, U = pol.states(), pol.controls()
+    n, m, N = 4, 2, 12
+    A, Bm, dt = pb.A[0], pb.Bm[0], pb.dt
+    Xr, Ur = pb.window(0)[0][0], pb.window(0)[1][0]
+    nz = n + m
+    nv = N * nz - m                       # z = (x_0, u_0, ..., x_{N-1})
+    g = np.zeros(nv)
+    for k in range(N):
+        g[k * nz:k * nz + n] = (10.0 * dt if k < N - 1 else 10.0) * (X[k] - Xr[k])
+        if k < N - 1:
+            g[k * nz + n:(k + 1) * nz] = 0.1 * dt * (U[k] - Ur[k])
+    rows = []
+    for i in range(n):                    # x_0 - x0
+        r = np.zeros(nv); r[i] = 1.0; rows.append(r)
+    nact = 0
+    for k in range(N - 1):
+        for side, sgn in ((0, 1.0), (1, -1.0)):          # u - 3 <= 0, -3 - u <= 0, active within 1e-3
+            for i in range(m):
+                c = sgn * U[k, i] - pb.u_bnd
+                if c >= -1e-3:
+                    r = np.zeros(nv); r[k * nz + n + i] = sgn; rows.append(r); nact += 1
+        for i in range(n):                # A x_k + B u_k - x_{k+1}
+            r = np.zeros(nv)
+            r[k * nz:k * nz + n] = A[i]; r[k * nz + n:(k + 1) * nz] = Bm[i]; r[(k + 1) * nz + i] -= 1.0
+            rows.append(r)
+    D = np.array(rows)
+    assert nact >= 2                      # the problem saturates: the projection has bound rows to deal with
+    lam = -np.linalg.solve(D @ D.T, D @ g)
+    res = np.linalg.norm(g + D.T @ lam)
+    assert abs(sp.pn_dual_residual - res) <= 1e-7 * max(1.0, np.linalg.norm(g)), (sp.pn_dual_residual, res)
+    assert sp.pn_dual_residual < 1e-6 * np.linalg.norm(g) and sp.pn_dual_residual0 > 0.1 * np.linalg.norm(g)
