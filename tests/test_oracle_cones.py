@@ -185,6 +185,11 @@ def test_grasp_mpc_iteration_statistics_against_reference(oracle):
         against 3.3-4.0) -- 20 % of its solves take 7+ iterations where 5 % of the reference's do.  The
         converged answers agree (the stored grasp trajectory is reproduced to 3e-7 above); what differs is
         Altro.jl's iterate path on cold duals at penalty 1e4, which nothing in the reference records.
+    Round 4: the AL active-set tolerance (Altro's active_set_tolerance_al = 1e-3: rows with c >= -tol count as active)
+    was tried in the restatement and moves the means by less than 0.2 either way -- not the cause.  The Gauss-Newton
+    variant is the closer one HERE (4.3-4.9) but cannot be the default: on BASELINE configs[2] (rocket landing,
+    N_mpc = 100, batch 4096) it triples the iterations per solve (102 against 34) and loses 2 % of the solves
+    (tools/debug/gpu_rocket_so2.py), while the curvature term reproduces the stored rocket step.
     The bounds below pin today's behaviour so that a change of the restatement shows up here."""
     import json
     import os
@@ -201,7 +206,7 @@ def test_grasp_mpc_iteration_statistics_against_reference(oracle):
     Xt, Ut = cold.states(), cold.controls()
     for Nm, seed in ((11, 1), (31, 2), (51, 3)):
         steps = 251 - Nm
-        for so2, gap, med_hi in ((0, 1.3, 4), (1, 2.4, 5)):     # Gauss-Newton cone Hessian / with the curvature term
+        for so2, gap, med_hi in ((0, 1.0, 4), (1, 1.9, 5)):     # Gauss-Newton cone Hessian / with the curvature term (observed: 4.3-4.9 / 5.1-5.7)
             its, ok = _grasp_mpc_iterations(oracle, gp, Xt, Ut, Nm, steps, seed, so2)
             assert ok >= steps - 2, (Nm, ok)                    # SOLVE_SUCCEEDED (the reference's loop does not check)
             assert its.min() == 2 and 3 <= np.median(its) <= med_hi, (Nm, so2, np.median(its), its.min())
