@@ -58,7 +58,7 @@ struct altro_handle {
   double *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Zref = nullptr, *Z = nullptr, *Lb = nullptr, *mu = nullptr,
          *KD = nullptr, *Qz = nullptr, *Dff = nullptr, *kmu = nullptr;
-  altro::AHash* ahash = nullptr;  // [Bp][16] active set of the backward pass behind the gains in KD (gain reuse, solve_dpp16.h)
+  altro::ASet* ahash = nullptr;  // [Bp][16] active set of the backward pass behind the gains in KD (gain reuse, solve_dpp16.h)
   long long* n_fo = nullptr;
   // projected-Newton polish (pn_polish.h): per-instance results and the workspace, allocated by the first solve that asks for it
   int *pn_ran = nullptr, *pn_failed = nullptr, *pn_dfail = nullptr;
@@ -783,8 +783,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->Qz, (N + 1) * row * sizeof(double)));
     CCHK(hipMalloc(&h->Dff, (N + 1) * row * sizeof(double)));
     CCHK(hipMemsetAsync(h->Dff, 0, (N + 1) * row * sizeof(double), h->stream));
-    CCHK(hipMalloc(&h->ahash, row * sizeof(altro::AHash)));
-    CCHK(hipMemsetAsync(h->ahash, 0, row * sizeof(altro::AHash), h->stream));
+    CCHK(hipMalloc(&h->ahash, row * sizeof(altro::ASet)));
+    CCHK(hipMemsetAsync(h->ahash, 0, row * sizeof(altro::ASet), h->stream));
     CCHK(hipMalloc(&h->kmu, Bp * sizeof(double)));
     CCHK(hipMalloc(&h->n_fo, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->pn_ran, Bp * sizeof(int)));

@@ -95,11 +95,16 @@ namespace altro {
 constexpr int LW = 16;  // lanes per instance (one DPP row)
 constexpr int IPW = 4;  // instances per wave
 
-// Active-set hash of one lane (see Solver::hash_add)
-struct AHash {
-  unsigned a, b;
+// The EXACT active set of one lane: two bits per knot (which sides of the lane's box entered the Hessian), 16 knots per
+// word, N <= 128 knots.  It guards the gains kept in KD for reuse -- across solves and launches -- so it is compared
+// bit for bit, not through a hash (rounds 2-3: 32-, then 64-bit hashes).  Kept in LDS while a launch runs (the sweeps
+// OR their knots into it with ds_or_b32: no registers, the same two VALU instructions per knot the hash took) and in
+// SolveParams::ahash between launches.  Longer horizons do not reuse gains (Solver::run, kvalid).
+constexpr int ASET_WORDS = 8;
+constexpr int ASET_MAXN = 16 * ASET_WORDS;
+struct ASet {
+  unsigned w[ASET_WORDS];
 };
-__device__ __forceinline__ bool operator!=(const AHash& x, const AHash& y) { return (x.a != y.a) | (x.b != y.b); }
 
 struct SolveParams {
   int B, Bp, N;
@@ -158,7 +163,7 @@ struct SolveParams {
   double* KD;            // [Bp][N][NU][16] gains: row a = K[a][0..NX-1] in the x lanes; lane NX + b (b <= a) holds entry (a, b) of
                          // the factors of Quu = L D L' (1 / D_a on the diagonal, L below it); block N-1 = trash
   double* Dff;           // [Bp][N+1][16] feedforward terms: d[a] on lane NX + a (knot N = trash)
-  AHash* ahash;          // [Bp][16] per lane: active set of the backward pass that left the gains in KD (kept between launches)
+  ASet* ahash;           // [Bp][16] per lane: active set of the backward pass that left the gains in KD (kept between launches)
   double* kmu;           // [Bp] penalty of that pass; < 0: the gains in KD must not be reused
   long long* n_fo;       // [Bp] iterations that took their gains from memory (first-order sweep instead of a backward pass)
   int* iters;
@@ -388,9 +393,6 @@ struct RowState {
   int gconf;      // the last iteration of the last solve was confirmed by the costate sweep (its d is exactly 0)
   int ngc;        // iterations confirmed by the costate sweep (work counter)
   int nfo;        // iterations that took their gains from memory (work counter)
-#ifdef ALTRO_DIAG_REUSE
-  double bwmu;
-#endif
 };
 
 template <int NX, int NU, bool CONES>
@@ -405,11 +407,9 @@ struct Solver {
   bool heavy_half = false; // wave-uniform: upper half of a grouped launch (see ALTRO_PRIO_HEAVY)
   int turns = 0;           // turns of the wave loop so far
   int n_lone = 0;          // backward passes of this launch that ran as backward_lone (diagnostic, wave_cycles[7])
-#ifdef ALTRO_DIAG_REUSE
-  int d_same0 = 0, d_same1 = 0, d_all0 = 0, d_all1 = 0;  // passes whose active set and penalty equal the row's previous pass (first / later iteration)
-#endif
-  AHash* ah;   // this lane's active-set hash of the backward pass that left the gains in KD (LDS; kept in P.ahash between launches)
-  AHash* qhs;  // this lane's active-set hash of the trajectory in Qz (LDS)
+  ASet* ah;    // this lane's active set of the backward pass that left the gains in KD (LDS; kept in P.ahash between launches)
+  ASet* qhs;   // this lane's active set of the trajectory in Qz (LDS)
+  ASet* atr;   // this lane's trash set: where a row that sits a phase out accumulates
   int lane, j, inst;
   bool is_x, is_u;
   unsigned rowoff;   // inst*16 + j          (element offsets are 32-bit: the host checks
@@ -424,10 +424,11 @@ struct Solver {
     bool has_hi, has_lo;
   };
 
-  __device__ Solver(const SolveParams& p, RowState* rows, double* tiles, AHash* hashes) : P(p) {
+  __device__ Solver(const SolveParams& p, RowState* rows, double* tiles, ASet* hashes) : P(p) {
     lane = threadIdx.x & 63;
     ah = hashes + (threadIdx.x & 63);
     qhs = hashes + 64 + (threadIdx.x & 63);
+    atr = hashes + 128 + (threadIdx.x & 63);
     j = lane & 15;
     inst = blockIdx.x * IPW + (lane >> 4);
     if (P.perm != nullptr) inst = P.perm[inst];
@@ -547,17 +548,19 @@ struct Solver {
     else __builtin_amdgcn_s_setprio(0);
   }
 
-  // Active-set hash of one lane: a position-weighted sum of the 2-bit codes, so that the backward pass (knots in
-  // descending order) and the rollout (ascending) arrive at the same number for the same active set.
-  // Two independent 32-bit sums (64 bits per lane): the hash of the gains in memory is compared with the active sets of
-  // unrelated later solves, launch after launch (gain reuse), so a collision must be out of reach, not just unlikely
-  // within one solve.
-  static __device__ __forceinline__ AHash hash_add(AHash h, unsigned code, int k) {
-    const unsigned ka = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;   // 24 bits: v_mad_u32_u24 runs at full rate
-    const unsigned kb = (((unsigned)(2 * k + 1)) * 2246822519u) >> 8;
-    h.a += __umul24(code, ka);
-    h.b += __umul24(code, kb);
-    return h;
+  // The active set of one lane is built knot by knot, in whatever order a sweep walks them (ASet above): OR is order-free,
+  // so the backward pass (descending), the rollouts (ascending) and the lone rollouts (four rows at once, each its own
+  // knots, into the SAME set: hence the atomic) arrive at the same words.
+  static __device__ __forceinline__ void aset_clear(ASet* t) {
+    sfor<0, ASET_WORDS>([&](auto q) { t->w[decltype(q)::value] = 0u; });
+  }
+  static __device__ __forceinline__ void aset_add(ASet* t, unsigned code, int k) {
+    atomicOr(&t->w[imin(k >> 4, ASET_WORDS - 1)], code << ((k & 15) * 2));
+  }
+  static __device__ __forceinline__ bool aset_ne(const ASet* a, const ASet* b) {
+    unsigned d = 0u;
+    sfor<0, ASET_WORDS>([&](auto q) { d |= a->w[decltype(q)::value] ^ b->w[decltype(q)::value]; });
+    return d != 0u;
   }
 
   // max over the NU control lanes of this row
@@ -610,7 +613,6 @@ struct Solver {
     bool limit;
     bool unchanged;  // the trial reproduced plane `cur` bit for bit (closed-loop rollouts only)
     bool tiny;       // every element moved by at most 1e-7 (1 + |z|)            (closed-loop rollouts only)
-    AHash qh;        // per lane: hash of the active set at the trajectory produced (box-only kernels)
   };
 
   struct KnotIn {
@@ -654,7 +656,8 @@ struct Solver {
     // (J0 + J1) + (J2 + J3) + terminal: rollout_lone(), where DPP row r evaluates exactly class r, gives the same bits.
     double Jcls[4] = {0.0, 0.0, 0.0, 0.0}, Jterm = 0.0, viol = 0.0;
     bool limit = false, changed = false, big = false;
-    AHash qh = {0u, 0u};
+    ASet* const tq = storeq ? qhs : atr;      // the active set at the trajectory produced: rows that take part own it afterwards
+    if constexpr (!CONES) aset_clear(tq);
     const int k1 = P.box_k1;
     const bool shl = OPEN && shift;           // per row
     const bool shu = shl && !is_x;            // controls are read one knot ahead
@@ -770,7 +773,7 @@ struct Solver {
         double qz;
         unsigned code;
         Jacc += lane_cost_grad<true>(lc, mu, zb, in.zr, lc.wd, OPEN ? lhi : in.lhi, OPEN ? llo : in.llo, bx, viol, qz, code);
-        qh = hash_add(qh, code, k);
+        aset_add(tq, code, k);
         stg(P.Qz, qat(storeq ? k : N), qz);
       } else {
         Jacc += lane_cost(lc, mu, zb, in.zr, lc.wd, lhi, llo, bx, viol);
@@ -848,7 +851,7 @@ struct Solver {
         double qz;
         unsigned code;
         Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
-        qh = hash_add(qh, code, kt);
+        aset_add(tq, code, kt);
         stg(P.Qz, qat(storeq ? kt : N), is_x ? qz : 0.0);
       } else {
         Jcls[0] += lane_cost(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol);
@@ -873,7 +876,6 @@ struct Solver {
     r.limit = row_any(limit, lane);
     r.unchanged = !row_any(changed, lane);
     r.tiny = !row_any(big, lane);
-    r.qh = qh;
     prio_base();
     return r;
   }
@@ -908,7 +910,8 @@ struct Solver {
     double xb = ldg(P.x0, rowoff);
     double Jc = 0.0, Jterm = 0.0, viol = 0.0;
     bool limit = false, changed = false, big = false;
-    AHash qh = {0u, 0u};
+    ASet* const tq = qhs;                // (lone_enter has pointed it at the lone row's set: the four rows OR their knots into it)
+    aset_clear(tq);
     const int k1 = P.box_k1;
     const bool shu = shift && !is_x;     // controls are read one knot ahead
     const bool wl = shift && bounded;    // shifted duals are written back
@@ -1027,7 +1030,7 @@ struct Solver {
       unsigned code;
       // an invalid knot (past the last stage knot) contributes exact zeros: weight 0, box off
       Jc += lane_cost_grad<true>(lc, mu, zm, c.zr, valid ? lc.wd : 0.0, lhi, llo, bx, viol, qz, code);
-      qh = hash_add(qh, code, kq);
+      aset_add(tq, valid ? code : 0u, kq);
       stg(P.Qz, qat(valid ? kq : N), qz);
       limit = limit | (valid & (is_x | is_u) & !(fabs(zm) <= lim));
     };
@@ -1065,7 +1068,7 @@ struct Solver {
       double qz;
       unsigned code;
       Jterm += lane_cost_grad<true>(lc, mu, zb, t_zr, lc.wf, bx ? t_lhi : 0.0, bx ? t_llo : 0.0, bx & is_x, viol, qz, code);
-      if (rr == 0) qh = hash_add(qh, code, kt);   // once: the rows' partial hashes are added below
+      aset_add(tq, code, kt);   // (every row, the same bits: idempotent)
       stg(P.Qz, qat(kt), is_x ? qz : 0.0);
       limit = limit | (is_x & !(fabs(zb) <= P.o.max_state_value));
       if constexpr (!OPEN) {
@@ -1079,16 +1082,6 @@ struct Solver {
     r.limit = wave_any(limit);
     r.unchanged = !wave_any(changed);
     r.tiny = !wave_any(big);
-    {  // the hash of the whole trajectory: sum of the rows' partial sums (mod 2^32)
-      double o[4];
-      rows_gather(__hiloint2double((int)qh.b, (int)qh.a), o);
-      unsigned a = 0u, b = 0u;
-      sfor<0, 4>([&](auto q) {
-        a += (unsigned)__double2loint(o[decltype(q)::value]);
-        b += (unsigned)__double2hiint(o[decltype(q)::value]);
-      });
-      r.qh = AHash{a, b};
-    }
     prio_base();
     return r;
   }
@@ -1355,7 +1348,8 @@ struct Solver {
       Blk<NX, NU>::HC(hh, acol, y);
     };
     // terminal expansion: S = Qf (+ box / cone hessian), s = Qf (x - xr) (+ box / cone gradient)
-    AHash hash = {0u, 0u};  // of the active set this pass sees, knot by knot
+    ASet* const ta = live ? ah : atr;   // the active set this pass sees, knot by knot
+    aset_clear(ta);
     double Sx[NX + 1];
     {
       const int k = N - 1;
@@ -1365,7 +1359,7 @@ struct Solver {
       double qz = lc.wf * (z - zr), hz = lc.wf;
       unsigned codeT;
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
-      hash = hash_add(hash, codeT, k);
+      aset_add(ta, codeT, k);
       if constexpr (CONES) {
         double hT[NZ];
         sfor<0, NZ>([&](auto c) {
@@ -1421,7 +1415,7 @@ struct Solver {
       double qz = lc.wd * (z - zr), hz = lc.wd;
       unsigned code;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      hash = hash_add(hash, code, k);
+      aset_add(ta, code, k);
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
       double w[NX + 1];
       sfor<0, NX + 1>([&](auto c) { w[decltype(c)::value] = 0.0; });
@@ -1552,18 +1546,6 @@ struct Solver {
       lcc = lcn;
     }
     dtiny = !row_any(dbig, lane);
-#ifdef ALTRO_DIAG_REUSE
-    {
-      const bool same = !row_any(hash != *ah, lane) && (rs->bwmu == mu) && !RHO;
-      const bool first = rs->it == 0;
-      d_same0 += __popcll(__ballot(live && same && first && j == 0));
-      d_same1 += __popcll(__ballot(live && same && !first && j == 0));
-      d_all0 += __popcll(__ballot(live && first && j == 0));
-      d_all1 += __popcll(__ballot(live && !first && j == 0));
-      if (live) rs->bwmu = RHO ? -1.0 : mu;
-    }
-#endif
-    if (live) *ah = hash;
   }
 
   // Gains of one knot out (kk / kf: the knot, or the trash slots N-1 of KD and N of Dff for rows that sit the pass out).
@@ -1749,15 +1731,17 @@ struct Solver {
     unsigned rowoff;
     RowState* rs;
     double* sm;
-    AHash* ah;
+    ASet* ah;
+    ASet* qhs;
   };
   __device__ __forceinline__ LoneCtx lone_enter(int lrow) {
-    LoneCtx c{inst, rowoff, rs, sm, ah};
+    LoneCtx c{inst, rowoff, rs, sm, ah, qhs};
     inst = __builtin_amdgcn_readlane(inst, lrow * LW);
     rowoff = (unsigned)inst * LW + j;
     rs = c.rs - (lane >> 4) + lrow;
     sm = c.sm - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
     ah = c.ah - lane + lrow * LW + j;
+    qhs = c.qhs - lane + lrow * LW + j;
     return c;
   }
   __device__ __forceinline__ void lone_leave(const LoneCtx& c) {
@@ -1766,6 +1750,7 @@ struct Solver {
     rs = c.rs;
     sm = c.sm;
     ah = c.ah;
+    qhs = c.qhs;
   }
   // Shadow rows.  The four rows of a wave run every phase together, and a row that sits a phase out used to run it on its
   // own instance: real loads of operands nobody needs (a fifth of the kernel's HBM traffic).  It now takes the identity of a
@@ -1774,7 +1759,7 @@ struct Solver {
   // trash slots (its own flags still say "not mine").  Results cannot change: the caller reads a phase's outputs only for
   // the rows that asked for it.
   __device__ __forceinline__ LoneCtx shadow_enter(bool active) {
-    LoneCtx c{inst, rowoff, rs, sm, ah};
+    LoneCtx c{inst, rowoff, rs, sm, ah, qhs};
     if (P.shadow == 0) return c;
     const unsigned long long bm = __ballot(active);
     if (bm == 0ull) return c;
@@ -1836,7 +1821,8 @@ struct Solver {
       diag_u[U] = (rr * RQ + U < NU) & (j == NX + rr * RQ + U);
     });
     const int psrc = (lane & 48) + ((rr * RL + j) & 15);  // lane whose [Qux] entry slot j of this row's S rows needs
-    AHash hash = {0u, 0u};
+    ASet* const ta = ah;   // (lone_enter has pointed it at the lone row's set; every DPP row ORs the same bits)
+    aset_clear(ta);
     double Sl[RL + 1];
     {
       const int k = N - 1;
@@ -1846,7 +1832,7 @@ struct Solver {
       double qz = lc.wf * (z - zr), hz = lc.wf;
       unsigned codeT;
       box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
-      hash = hash_add(hash, codeT, k);
+      aset_add(ta, codeT, k);
       sfor<0, RL>([&](auto t) { Sl[decltype(t)::value] = diag_x[decltype(t)::value] ? hz : 0.0; });
       Sl[RL] = (is_x & (rr == 0)) ? qz : 0.0;
     }
@@ -1866,7 +1852,7 @@ struct Solver {
       double qz = lc.wd * (z - zr), hz = lc.wd;
       unsigned code;
       box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      hash = hash_add(hash, code, k);
+      aset_add(ta, code, k);
       // this row's rows of W = [S; s'] G
       double wl[RL + 1];
       sfor<0, RL + 1>([&](auto t) { wl[decltype(t)::value] = 0.0; });
@@ -1995,18 +1981,6 @@ struct Solver {
       llo = llon;
     }
     dtiny = !row_any(dbig, lane);
-#ifdef ALTRO_DIAG_REUSE
-    {
-      const bool same = !row_any(hash != *ah, lane) && (rs->bwmu == mu);
-      const bool first = rs->it == 0;
-      d_same0 += (same && first) ? 1 : 0;
-      d_same1 += (same && !first) ? 1 : 0;
-      d_all0 += first ? 1 : 0;
-      d_all1 += first ? 0 : 1;
-      rs->bwmu = mu;
-    }
-#endif
-    *ah = hash;
   }
 
   // Costate sweep (default mode, box-only problems): lambda_N = l_x(N), lambda_k = l_x(k) + A' lambda_{k+1},
@@ -2152,11 +2126,9 @@ struct Solver {
       s.gconf = P.dzero[inst];
       s.ngc = 0;
       s.nfo = 0;
-#ifdef ALTRO_DIAG_REUSE
-      s.bwmu = -1.0;
-#endif
       *rs = s;
       *ah = P.ahash[(unsigned)inst * LW + j];
+      aset_clear(qhs);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -2245,7 +2217,6 @@ struct Solver {
             rs->dj_zero = 0;
             rs->it = 0;
             rs->qvalid = CONES ? 0 : 1;  // the open-loop rollout left l_z and the active-set hash of its trajectory
-            if constexpr (!CONES) *qhs = r0.qh;
             rs->shift = 0;
             rs->nro += 1;
             rs->J_prev = r0.J;
@@ -2304,7 +2275,7 @@ struct Solver {
             // current trajectory, left by the rollout that produced it, against the hash of the pass that wrote KD), same
             // penalty, no regularisation.  The problem is quadratic inside an active set, K does not depend on the iterate;
             // the pass may be one of an earlier solve or an earlier launch (gain reuse).
-            const bool same = !row_any(*qhs != *ah, lane);
+            const bool same = !row_any(aset_ne(qhs, ah), lane) && (P.N <= ASET_MAXN);
             const bool kvalid = !o.strict && inner && (rs->qvalid != 0) && same && (rs->rho == 0.0) && (rs->kmu == rs->mu);
             const bool tryg = kvalid && (rs->it >= 1) && (rs->grad_tol > 1e-8) && (rs->cost_tol > 1e-10 * (1.0 + fabs(rs->J_prev)));
             if (wave_any(tryg)) {
@@ -2471,7 +2442,6 @@ struct Solver {
             if (searching) {
               rs->nro += 1;
               trial(1.0, rr.J, rr.cmax, rr.limit, rr.unchanged, rr.tiny);
-              *qhs = rr.qh;
               rs->qvalid = (accepted && alpha == 1.0) ? 1 : 0;  // a smaller step (or none) leaves Qz describing a rejected trial
             }
           }
@@ -2673,7 +2643,7 @@ template <int NX, int NU, bool CONES>
 __global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SIMD) solve_kernel(SolveParams p) {
   __shared__ double tiles[IPW * LW * (LW + 1)];
   __shared__ RowState rows[IPW];
-  __shared__ altro::AHash hashes[128];
+  __shared__ altro::ASet hashes[192];   // per lane: the pass's active set, the trajectory's, a trash set
   const long long t0 = __builtin_amdgcn_s_memtime();
   Solver<NX, NU, CONES> s(p, rows, tiles, hashes);
   ALTRO_STAMP(s.t_start = t0;)
@@ -2692,9 +2662,6 @@ __global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SI
       const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 0xf;
       wc[4] = (long long)((x << 12) | (((a >> 13) & 7) << 9) | (((a >> 12) & 1) << 8) | (((a >> 8) & 15) << 2) | ((a >> 4) & 3));
     }
-#endif
-#ifdef ALTRO_DIAG_REUSE
-    wc[3] = s.d_same0; wc[4] = s.d_all0; wc[5] = s.d_same1; wc[6] = s.d_all1;
 #endif
   }
 }

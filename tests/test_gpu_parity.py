@@ -1393,7 +1393,7 @@ def test_scheduling_switches_do_not_change_results(monkeypatch):
     wave in step (ALTRO_NO_RESYNC), the lone-row pass (ALTRO_NO_LONE) and idle rows shadowing a busy one (ALTRO_NO_SHADOW) decide
     WHEN, in WHICH wave and on whose operands a row idles, never what it computes: every output is the same bit for bit.  Gain reuse (ALTRO_NO_REUSE) changes the arithmetic of an
     iteration (first-order recursion with the stored gains instead of a backward pass): same statuses and iteration
-    counts, trajectories equal to 1e-9."""
+    counts, trajectories equal to 1e-12."""
     B, S = 150, 14
     pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=31)
 
@@ -1422,8 +1422,10 @@ def test_scheduling_switches_do_not_change_results(monkeypatch):
     assert int(altro.reuse_counter(b.solver).sum()) == 0
     sb = altro.stats(b.solver)
     assert np.array_equal(sa.iterations, sb.iterations) and np.array_equal(sa.status, sb.status)
-    assert rel_err(Xa, altro.states(b.solver)) <= 1e-9 and rel_err(Ua, altro.controls(b.solver)) <= 1e-9
-    assert np.abs(sa.cost - sb.cost).max() <= 1e-9 * max(1.0, np.abs(sb.cost).max())
+    ex, eu = rel_err(Xa, altro.states(b.solver)), rel_err(Ua, altro.controls(b.solver))
+    print("gain reuse on / off over %d steps of %d instances: X %.1e, U %.1e" % (S, B, ex, eu))
+    assert ex <= 1e-12 and eu <= 1e-12    # (the stored gains are guarded by the exact active set: a reused K IS the K a pass would compute)
+    assert np.abs(sa.cost - sb.cost).max() <= 1e-12 * max(1.0, np.abs(sb.cost).max())
     ia, ib = altro.solve_counters(a.solver)[1], altro.solve_counters(b.solver)[1]
     assert np.array_equal(ia, ib)               # iteration counts over all 14 steps, instance by instance
 
