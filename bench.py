@@ -261,6 +261,20 @@ def _secondary_line(name, workload, kernel, bound, n, m, N, B, K, W, mp, altro, 
     return out
 
 
+def _next_window(mp, altro, K, first, B):
+    """The K steps after a line's own, same options: a launch lasts as long as its slowest instance, and single solves of a
+    few hundred iterations (0.05 % of them, the oracle walks the same counts) fall into some windows and not into others"""
+    altro.timing_reset(mp.solver)
+    t0 = time.perf_counter()
+    mp.run_async(K, first=first)
+    mp.synchronize()
+    dt = time.perf_counter() - t0
+    nsol, nit, nok = altro.solve_counters(mp.solver)
+    return {"value": B * K / dt, "unit": "solves/s", "steps": K, "ms_per_step": 1e3 * dt / K, "solve_succeeded_frac": float(nok.sum() / max(1, nsol.sum())),
+            "iterations_mean": float(nit.sum() / max(1, nsol.sum())), "iterations_max_per_instance": int(nit.max()),
+            "note": "the next K steps of the same closed loops, same options"}
+
+
 def _capped(mp, altro, cap, K, W, B):
     """The same closed loops once more with Altro's `iterations` option (the total iLQR iterations one solve may take,
     default 1000) set to `cap`, as an MPC deployment with a tick deadline would: a solve that hits it reports
@@ -269,7 +283,7 @@ def _capped(mp, altro, cap, K, W, B):
     altro.set_options(mp.solver, iterations=cap)
     altro.timing_reset(mp.solver)
     t0 = time.perf_counter()
-    mp.run_async(K, first=W + K)
+    mp.run_async(K, first=mp.i)
     mp.synchronize()
     dt = time.perf_counter() - t0
     nsol, nit, nok = altro.solve_counters(mp.solver)
@@ -330,17 +344,18 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64), gr
             # launch configuration of the point in the committed profile: one wave per four instances (n = 8), per instance
             # (n <= 48) or a cooperative block of four waves per instance (wide_block_threads)
             wg = 256 if n > 48 else 64
+            # (n = 32 and n = 48 share kernel, grid and block: the profile tells them apart by their order, `point`)
             tk = ("state_dim", "solve_kernel<8, 4" if n == 8 else "wide_kernel<4, true>" if n <= 16 else "wide_kernel<4, false>",
-                  {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg})
+                  {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg, "point": 1 if n == 48 else 0})
             done(_secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
                                  kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro, traffic_key=tk, grp=grp))
             mp.solver.close()
     if which in ("quadruped", "all"):   # configs[4]: quadruped contact-switching MPC, N = 40, 2048 instances per GPU, LTV loop on device
         B, N = 2048, 40                   # configs[4]: 16384 instances over 8 GPUs
         K4 = min(K, 20)
-        qb = P.gen_quadruped_batch(B, N=N, steps=W + 2 * K4, seed=17, first_instance=shard0(grp.rank, B))
+        qb = P.gen_quadruped_batch(B, N=N, steps=W + 3 * K4, seed=17, first_instance=shard0(grp.rank, B))
         qp, x0, A, Bm, d = qb.qp, qb.x0, qb.A, qb.Bm, qb.d
-        Nt = W + 2 * K4 + N + 1
+        Nt = W + 3 * K4 + N + 1
         prob = mpcm.quadruped_problem(qp, x0, A[:, :N - 1], Bm[:, :N - 1], d[:, :N - 1])
         mp = mpcm.TrackMPC(prob, api.SolverOptions(**P.QUADRUPED_OPTS), np.tile(qp.x_des, (B, Nt, 1)), np.zeros((B, Nt - 1, 12)),
                            qb.noise, (np.full(12, 1e-3),), device=device)
@@ -350,6 +365,7 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64), gr
         line = _secondary_line("quadruped contact-switching MPC N=40", "quadruped N=40 batch=2048 on 1 GPU, per-knot dynamics resident on the device (BASELINE configs[4])",
                                "altro_wide::wide_kernel<12>", "valu_fp64+mfma", 12, 12, N, B, K4, W, mp, altro, traffic_key=("quadruped", "wide_kernel"), grp=grp)
         if grp.world == 1:
+            line["next_window"] = _next_window(mp, altro, K4, W + K4, B)
             line["with_iteration_cap"] = _capped(mp, altro, 50, K4, W, B)
         done(line)
         mp.solver.close()

@@ -51,19 +51,32 @@ for name in ("quadruped", "state_dim", "rocket"):
     kt = find(name + "/kt", "*kernel_trace.csv")
     durs = {}
     if kt:
-        for r in csv.DictReader(open(kt)):
-            if any(k in r["Kernel_Name"] for k in KERNELS):
-                durs.setdefault(sig_of(r, True), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        rows = sorted((r for r in csv.DictReader(open(kt)) if any(k in r["Kernel_Name"] for k in KERNELS)), key=lambda r: int(r["Start_Timestamp"]))
+        last_end = {}
+        for r in rows:
+            sig = sig_of(r, True)
+            t0, t1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            # sweep points that share a kernel AND a launch configuration (n = 32 and n = 48 of the state-dimension sweep: the
+            # trace does not report dynamic LDS) are told apart by the pause between them (the next point's problems are
+            # generated on the host): a new group of dispatches after more than 0.3 s
+            if sig not in durs or t0 - last_end[sig] > 300e6:
+                durs.setdefault(sig, []).append([])
+            durs[sig][-1].append(t1 - t0)
+            last_end[sig] = t1
     fe, wr, sq = counters(name + "/fetch"), counters(name + "/write"), counters(name + "/sq")
-    for sig, ds in durs.items():
-        # the timed (fused) launch of each line is the longest dispatch of its kernel and launch configuration
+    for sig, groups in durs.items():
+      for point, ds in enumerate(groups):
+        # the timed (fused) launch of each line is the longest dispatch of its kernel, launch configuration and sweep point
         i = max(range(len(ds)), key=lambda j: ds[j])
-        rec = {"kernel": sig[0], "grid_size": sig[1], "workgroup_size": sig[2], "lds_block_size": sig[3], "dispatches": len(ds),
+        rec = {"kernel": sig[0], "grid_size": sig[1], "workgroup_size": sig[2], "lds_block_size": sig[3], "point": point, "dispatches": len(ds),
                "timed_launch_ms": ds[i] / 1e6}
         for src in (fe, wr, sq):
             disp = src.get(sig, {})
             if disp:
-                best = max(disp.items(), key=lambda kv: sum(kv[1].values()))[1]   # the same (largest) launch in the PMC pass
+                ids = sorted(disp)   # the PMC passes replay the same dispatch sequence: the same share of it is this sweep point's
+                per = max(1, len(ids) // len(groups))
+                mine = ids[point * per:(point + 1) * per] if point < len(groups) - 1 else ids[point * per:]
+                best = max((disp[d] for d in mine), key=lambda c: sum(c.values()))   # the same (largest) launch in the PMC pass
                 rec.update(best)
         if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
             rec["hbm_bytes"] = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
