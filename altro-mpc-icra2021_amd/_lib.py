@@ -157,7 +157,7 @@ def lib():
 # `ALTRO_NO_LONE=1 python tools/...` and pytest's monkeypatch.setenv keep working.  (variable, key, default, negate)
 DEBUG_ENV = [
     ("ALTRO_NO_LONE", "no_lone", 0), ("ALTRO_NO_SHADOW", "no_shadow", 0), ("ALTRO_NO_RESYNC", "no_resync", 0),
-    ("ALTRO_NO_GROUP", "no_group", 0), ("ALTRO_NO_REUSE", "no_reuse", 0), ("ALTRO_GROUP_MAX_STEPS", "group_max_steps", 32),
+    ("ALTRO_NO_GROUP", "no_group", 0), ("ALTRO_NO_REUSE", "no_reuse", 0), ("ALTRO_NO_QZ_PASS", "no_qz_pass", 0), ("ALTRO_GROUP_MAX_STEPS", "group_max_steps", 32),
     ("ALTRO_DEBUG_TRACE_WAVE", "trace_wave", -1), ("ALTRO_FORCE_WIDE", "force_wide", 0),
     ("ALTRO_WIDE_COMPACT", "wide_compact", -1), ("ALTRO_WIDE_COOP", "wide_coop", -1),
     ("ALTRO_WIDE_STATIC_MASK", "wide_static_mask", -1), ("ALTRO_DEBUG_KEEP_GAINS", "keep_gains", 0),
@@ -176,7 +176,12 @@ def sync_debug_env():
     """forward the ALTRO_* diagnostic variables of the environment to altro_debug_set (defaults where unset)"""
     for var, key, default in DEBUG_ENV:
         v = os.environ.get(var)
-        debug_set(key, int(v) if v not in (None, "") else default)
+        try:
+            debug_set(key, int(v) if v not in (None, "") else default)
+        except AltroError as e:
+            # an older build of the library (ALTRO_HIP_LIB, the A/B tools) may not know a newer switch: fine while it is not asked for
+            if e.code != ERR_INVALID_ARG or v not in (None, ""):
+                raise
     gm = os.environ.get("ALTRO_GROUP_MODE")     # after no_group: a slot order switches grouping on
     if gm not in (None, ""):
         debug_set("group_mode", int(gm))

@@ -28,7 +28,7 @@ static thread_local std::string g_create_err;
 // a measuring tool that wants a scheduling feature off says so through the entry point -- with a null handle for the
 // handles this thread creates afterwards, with a handle for that handle.
 struct DebugSwitches {
-  int lone = 1, shadow = 1, resync = 1, reuse = 1;
+  int lone = 1, shadow = 1, resync = 1, reuse = 1, useqz = 1;
   int group = 1;             // 0 off, 1 sorted, 2-4: other slot orders (k_group_rank)
   int group_max_steps = 32;
   int trace_wave = -1;       // -DALTRO_PHASE_STAMPS builds
@@ -75,6 +75,7 @@ struct altro_handle {
   int lone = 1;  // backward_lone (solve_dpp16.h); "no_lone" switches it off (tests: lone == four-row pass bit for bit)
   int group_max_steps = 32;  // fused launches of more steps are not grouped ("group_max_steps": diagnostic)
   int shadow = 1;  // "no_shadow": rows that sit a phase out keep their own instance (solve_dpp16.h shadow_enter)
+  int useqz = 1;   // "no_qz_pass": backward passes always recompute their cost / box expansion (solve_dpp16.h backward QV)
   int* cur = nullptr;
   int *perm = nullptr, *gscore = nullptr;  // [Bp] wave slot -> instance of a grouped MPC launch, and its sort key
   bool debug_keep_gains = false;           // "keep_gains" (-DALTRO_DEBUG builds only): the setters do NOT drop the stored gains
@@ -465,7 +466,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.Gcol = h->Gcol; p.Grow = h->Grow; p.fvec = h->fvec;
   p.wd = h->wd; p.wf = h->wf; p.zmin = h->zmin; p.zmax = h->zmax;
   p.x0 = h->x0; p.Zref = h->Zref; p.Z = h->Z; p.cur = h->cur;
-  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.shadow = h->shadow; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
+  p.Lb = h->Lb; p.bslot = h->bslot; p.nbp = h->nbp; p.mu = h->mu; p.lone = h->lone; p.useqz = h->useqz; p.shadow = h->shadow; p.reuse = h->reuse; p.resync = h->resync; p.dbg_wave = h->dbg_wave;
   p.Dff = h->Dff; p.ahash = h->ahash; p.kmu = h->kmu; p.n_fo = h->n_fo;
   p.Qz = h->Qz;
   p.Acon = h->Acon; p.bcon = h->bcon; p.cmeta = h->cmeta; p.ckn = h->ckn; p.con_inv = h->con_inv;
@@ -595,9 +596,10 @@ int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value) {
     }
     DebugSwitches tmp;
     DebugSwitches& d = h ? tmp : g_dbg;
-    if (h) { tmp.lone = h->lone; tmp.shadow = h->shadow; tmp.resync = h->resync; tmp.reuse = h->reuse; tmp.group = h->group;
+    if (h) { tmp.lone = h->lone; tmp.useqz = h->useqz; tmp.shadow = h->shadow; tmp.resync = h->resync; tmp.reuse = h->reuse; tmp.group = h->group;
              tmp.group_max_steps = h->group_max_steps; tmp.trace_wave = h->dbg_wave; }
     if (k == "no_lone") d.lone = value ? 0 : 1;
+    else if (k == "no_qz_pass") d.useqz = value ? 0 : 1;
     else if (k == "no_shadow") d.shadow = value ? 0 : 1;
     else if (k == "no_resync") d.resync = value ? 0 : 1;
     else if (k == "no_reuse") d.reuse = value ? 0 : 1;
@@ -608,7 +610,7 @@ int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value) {
     else return bad(ALTRO_ERR_INVALID_ARG, "unknown switch");
     if (h && !h->wide) {
       const bool reuse_changed = h->reuse != tmp.reuse;
-      h->lone = tmp.lone; h->shadow = tmp.shadow; h->resync = tmp.resync; h->reuse = tmp.reuse; h->group = tmp.group;
+      h->lone = tmp.lone; h->useqz = tmp.useqz; h->shadow = tmp.shadow; h->resync = tmp.resync; h->reuse = tmp.reuse; h->group = tmp.group;
       h->group_max_steps = tmp.group_max_steps; h->dbg_wave = tmp.trace_wave;
       if (reuse_changed) { HIPCHK(h, hipSetDevice(h->device)); return drop_gains(h); }
     }
@@ -717,7 +719,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->d = *dims;
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
-    h->lone = g_dbg.lone; h->shadow = g_dbg.shadow; h->resync = g_dbg.resync; h->reuse = g_dbg.reuse; h->group = g_dbg.group;
+    h->lone = g_dbg.lone; h->useqz = g_dbg.useqz; h->shadow = g_dbg.shadow; h->resync = g_dbg.resync; h->reuse = g_dbg.reuse; h->group = g_dbg.group;
     h->group_max_steps = g_dbg.group_max_steps; h->dbg_wave = g_dbg.trace_wave; h->debug_keep_gains = g_dbg.keep_gains != 0;
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
     auto fail = [&](const char* what, hipError_t er) {

@@ -142,6 +142,7 @@ struct SolveParams {
   int reuse;             // 1: gain reuse (fosweep) allowed; ALTRO_NO_REUSE=1 at create time switches it off
   int shadow;  // rows that sit a phase out take the identity of a row that takes part (Solver::shadow_enter)
   int lone;              // 1: a backward pass that only one row of a wave needs runs spread over the four DPP rows (backward_lone)
+  int useqz;             // 1: a backward pass over a trajectory a rollout has just produced reads its expansion back from Qz (backward QV)
   // generic affine constraints (LINEAR eq/ineq, SOC): up to 16 constraint rows per knot, row r
   // on lane r, organised in 4 quads of 4 lanes; a quad is one cone (SOC of dimension <= 4, or
   // up to 4 independent equality / inequality rows).  Data is shared by all instances.
@@ -556,6 +557,20 @@ struct Solver {
   }
   static __device__ __forceinline__ void aset_add(ASet* t, unsigned code, int k) {
     atomicOr(&t->w[imin(k >> 4, ASET_WORDS - 1)], code << ((k & 15) * 2));
+  }
+  static __device__ __forceinline__ unsigned aset_get(const ASet* t, int k) {
+    return (t->w[imin(k >> 4, ASET_WORDS - 1)] >> ((k & 15) * 2)) & 3u;
+  }
+  static __device__ __forceinline__ void aset_copy(ASet* d, const ASet* s_) {
+    sfor<0, ASET_WORDS>([&](auto q) { d->w[decltype(q)::value] = s_->w[decltype(q)::value]; });
+  }
+  // Hessian diagonal of the lane's cost + box terms from the two bits of its active set: w + mu [upper side] + mu [lower side]
+  // (the sum box_expand forms, in its order)
+  static __device__ __forceinline__ double hz_of(double w, double mu, unsigned bits) {
+    double hz = w;
+    hz += (bits & 1u) ? mu : 0.0;
+    hz += (bits & 2u) ? mu : 0.0;
+    return hz;
   }
   static __device__ __forceinline__ bool aset_ne(const ASet* a, const ASet* b) {
     unsigned d = 0u;
@@ -1316,8 +1331,16 @@ struct Solver {
   // dtiny (out): every feedforward term of this pass is at rounding level, max_a |d_k,a| <= 1e-9 (1 + |u_k,a|) on
   // every control lane of every knot.  The step this pass proposes then moves nothing by more than ~1e-8: see the
   // "confirmation iteration" shortcut in run().
-  template <bool RHO, bool SYM>
+  // QV (box-only kernels, rho == 0): every row that takes part holds a trajectory a rollout has just produced -- then that
+  // rollout has left, per knot, exactly what the expansion would recompute: the gradient of the cost and box terms in the
+  // plane Qz (lane_cost_grad forms the sum box_expand forms, in its order) and the active set in qhs (two bits per knot:
+  // the Hessian diagonal is w + mu [upper] + mu [lower]).  The pass then reads ONE row per knot (plus z, for the test of
+  // the feedforward terms against |u|) instead of z, z_ref and both dual rows, and skips the expansion's ~35 instructions;
+  // its own active set IS the trajectory's.  Same values, same operations on them: bit-identical to the full expansion
+  // (tests: the lone and four-row passes, K fused steps against K launches, the oracle).
+  template <bool RHO, bool SYM, bool QV = false>
   __device__ void backward(double& dV1, double& dV2, bool& fail, bool& dtiny, bool live) {
+    static_assert(!QV || (!CONES && !RHO), "the Qz form of the pass: box-only kernels, no regularisation");
     phase_begin();
     const LaneConst lc = consts();
     const double mu = rs->mu;
@@ -1349,17 +1372,26 @@ struct Solver {
     };
     // terminal expansion: S = Qf (+ box / cone hessian), s = Qf (x - xr) (+ box / cone gradient)
     ASet* const ta = live ? ah : atr;   // the active set this pass sees, knot by knot
-    aset_clear(ta);
+    if constexpr (QV) aset_copy(ta, qhs);
+    else aset_clear(ta);
     double Sx[NX + 1];
     {
       const int k = N - 1;
-      const double z = ldg(P.Z, zs + zat(k));
-      const double zr = ldg(P.Zref, rat(kref + k));
-      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
-      double qz = lc.wf * (z - zr), hz = lc.wf;
-      unsigned codeT;
-      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
-      aset_add(ta, codeT, k);
+      double qz, hz;
+      double z = 0.0;
+      if constexpr (QV) {
+        qz = ldg(P.Qz, qat(k));
+        hz = hz_of(lc.wf, mu, aset_get(qhs, k));
+      } else {
+        z = ldg(P.Z, zs + zat(k));
+        const double zr = ldg(P.Zref, rat(kref + k));
+        const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
+        qz = lc.wf * (z - zr);
+        hz = lc.wf;
+        unsigned codeT;
+        box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
+        aset_add(ta, codeT, k);
+      }
       if constexpr (CONES) {
         double hT[NZ];
         sfor<0, NZ>([&](auto c) {
@@ -1386,8 +1418,12 @@ struct Solver {
     bool dbig = false;
     double* my = sm;
     // operands of the knot about to be processed (loaded one knot ahead)
-    double z = ldg(P.Z, zs + zat(N - 2)), zr = ldg(P.Zref, rat(kref + N - 2));
-    double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
+    double z = ldg(P.Z, zs + zat(N - 2)), zr = QV ? ldg(P.Qz, qat(N - 2)) : ldg(P.Zref, rat(kref + N - 2));   // QV: zr carries Qz
+    double lhi = 0.0, llo = 0.0;
+    if constexpr (!QV) {
+      lhi = ldg(P.Lb, lb_at(N - 2, 0));
+      llo = ldg(P.Lb, lb_at(N - 2, 1));
+    }
     double lcc = 0.0;
     // the knot's constraint table (this lane's row and column, 26+ loads from L2) is requested one knot
     // ahead like the other operands: the conic kernels run one wave per SIMD, nothing else hides it
@@ -1403,19 +1439,31 @@ struct Solver {
     // of them for all but the 4 youngest memory operations (`s_waitcnt vmcnt(4)` right after the body's own four loads),
     // i.e. for the FIVE GAIN STORES of the previous knot: one store round trip per knot, the reason the pass slowed down
     // by 40-80 % whenever the memory system was busy.
-    asm volatile("" : "+v"(z), "+v"(zr), "+v"(lhi), "+v"(llo));
+    asm volatile("" : "+v"(z), "+v"(zr));
+    if constexpr (!QV) asm volatile("" : "+v"(lhi), "+v"(llo));
     if constexpr (CONES) asm volatile("" : "+v"(lcc));
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + zat(km));
-      const double zrn = ldg(P.Zref, rat(kref + km));
-      const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
+      const double zrn = QV ? ldg(P.Qz, qat(km)) : ldg(P.Zref, rat(kref + km));
+      double lhin = 0.0, llon = 0.0;
+      if constexpr (!QV) {
+        lhin = ldg(P.Lb, lb_at(km, 0));
+        llon = ldg(P.Lb, lb_at(km, 1));
+      }
       double lcn = 0.0;
       if constexpr (CONES) lcn = ldg(P.Lc, qat(km));
-      double qz = lc.wd * (z - zr), hz = lc.wd;
-      unsigned code;
-      box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      aset_add(ta, code, k);
+      double qz, hz;
+      if constexpr (QV) {
+        qz = zr;
+        hz = hz_of(lc.wd, mu, aset_get(qhs, k));
+      } else {
+        qz = lc.wd * (z - zr);
+        hz = lc.wd;
+        unsigned code;
+        box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
+        aset_add(ta, code, k);
+      }
       // W = [S; s'] * G   (w[NX] = (G's)[lane])
       double w[NX + 1];
       sfor<0, NX + 1>([&](auto c) { w[decltype(c)::value] = 0.0; });
@@ -1770,6 +1818,9 @@ struct Solver {
     rs = active ? rs : c.rs - (lane >> 4) + lrow;
     sm = active ? sm : c.sm - (lane >> 4) * (LW * (LW + 1)) + lrow * (LW * (LW + 1));
     ah = active ? ah : c.ah - lane + lrow * LW + j;
+    // (the trajectory's active set too: a shadow must compute what its row computes -- in the strict pass all four rows
+    //  write the transpose tile of the row they shadow)
+    qhs = active ? qhs : c.qhs - lane + lrow * LW + j;
     return c;
   }
   // the row of the wave (0..3) a wave-uniform ballot of a per-row flag names, and how many rows it names
@@ -1785,7 +1836,7 @@ struct Solver {
     return __hiloint2double(hi, lo);
   }
 
-  template <bool SYM>
+  template <bool SYM, bool QV = false>   // QV: the expansion read back from Qz and the trajectory's active set (see backward())
   __device__ void backward_lone(double& dV1, double& dV2, bool& fail, bool& dtiny) {
     using BK = Blk<NX, NU>;
     constexpr int RL = BK::RL, RQ = BK::RQ;
@@ -1822,17 +1873,25 @@ struct Solver {
     });
     const int psrc = (lane & 48) + ((rr * RL + j) & 15);  // lane whose [Qux] entry slot j of this row's S rows needs
     ASet* const ta = ah;   // (lone_enter has pointed it at the lone row's set; every DPP row ORs the same bits)
-    aset_clear(ta);
+    if constexpr (QV) aset_copy(ta, qhs);
+    else aset_clear(ta);
     double Sl[RL + 1];
     {
       const int k = N - 1;
-      const double z = ldg(P.Z, zs + zat(k));
-      const double zr = ldg(P.Zref, rat(kref + k));
-      const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
-      double qz = lc.wf * (z - zr), hz = lc.wf;
-      unsigned codeT;
-      box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
-      aset_add(ta, codeT, k);
+      double qz, hz;
+      if constexpr (QV) {
+        qz = ldg(P.Qz, qat(k));
+        hz = hz_of(lc.wf, mu, aset_get(qhs, k));
+      } else {
+        const double z = ldg(P.Z, zs + zat(k));
+        const double zr = ldg(P.Zref, rat(kref + k));
+        const double lhi = ldg(P.Lb, lb_at(k, 0)), llo = ldg(P.Lb, lb_at(k, 1));
+        qz = lc.wf * (z - zr);
+        hz = lc.wf;
+        unsigned codeT;
+        box_expand(lc, mu, z, lhi, llo, box_at(k) & is_x, qz, hz, codeT);
+        aset_add(ta, codeT, k);
+      }
       sfor<0, RL>([&](auto t) { Sl[decltype(t)::value] = diag_x[decltype(t)::value] ? hz : 0.0; });
       Sl[RL] = (is_x & (rr == 0)) ? qz : 0.0;
     }
@@ -1841,18 +1900,34 @@ struct Solver {
     fail = false;
     bool dbig = false;
     double* my = sm;
-    double z = ldg(P.Z, zs + zat(N - 2)), zr = ldg(P.Zref, rat(kref + N - 2));
-    double lhi = ldg(P.Lb, lb_at(N - 2, 0)), llo = ldg(P.Lb, lb_at(N - 2, 1));
-    asm volatile("" : "+v"(z), "+v"(zr), "+v"(lhi), "+v"(llo));  // waited for once, outside the loop: see backward()
+    double z = ldg(P.Z, zs + zat(N - 2)), zr = QV ? ldg(P.Qz, qat(N - 2)) : ldg(P.Zref, rat(kref + N - 2));   // QV: zr carries Qz
+    double lhi = 0.0, llo = 0.0;
+    if constexpr (!QV) {
+      lhi = ldg(P.Lb, lb_at(N - 2, 0));
+      llo = ldg(P.Lb, lb_at(N - 2, 1));
+    }
+    asm volatile("" : "+v"(z), "+v"(zr));  // waited for once, outside the loop: see backward()
+    if constexpr (!QV) asm volatile("" : "+v"(lhi), "+v"(llo));
     for (int k = N - 2; k >= 0; --k) {  // body: one basic block
       const int km = imax(k - 1, 0);
       const double zn = ldg(P.Z, zs + zat(km));
-      const double zrn = ldg(P.Zref, rat(kref + km));
-      const double lhin = ldg(P.Lb, lb_at(km, 0)), llon = ldg(P.Lb, lb_at(km, 1));
-      double qz = lc.wd * (z - zr), hz = lc.wd;
-      unsigned code;
-      box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
-      aset_add(ta, code, k);
+      const double zrn = QV ? ldg(P.Qz, qat(km)) : ldg(P.Zref, rat(kref + km));
+      double lhin = 0.0, llon = 0.0;
+      if constexpr (!QV) {
+        lhin = ldg(P.Lb, lb_at(km, 0));
+        llon = ldg(P.Lb, lb_at(km, 1));
+      }
+      double qz, hz;
+      if constexpr (QV) {
+        qz = zr;
+        hz = hz_of(lc.wd, mu, aset_get(qhs, k));
+      } else {
+        qz = lc.wd * (z - zr);
+        hz = lc.wd;
+        unsigned code;
+        box_expand(lc, mu, z, lhi, llo, box_at(k), qz, hz, code);
+        aset_add(ta, code, k);
+      }
       // this row's rows of W = [S; s'] G
       double wl[RL + 1];
       sfor<0, RL + 1>([&](auto t) { wl[decltype(t)::value] = 0.0; });
@@ -2321,8 +2396,9 @@ struct Solver {
               double a1, a2;
               bool dt;
               if constexpr (!CONES) {
-                if (o.strict) backward_lone<true>(a1, a2, fail, dt);
-                else backward_lone<false>(a1, a2, fail, dt);
+                const bool useq = (P.useqz != 0) && (rs->qvalid != 0) && (P.N <= ASET_MAXN);   // (all lanes: the lone row's state)
+                if (o.strict) { if (useq) backward_lone<true, true>(a1, a2, fail, dt); else backward_lone<true, false>(a1, a2, fail, dt); }
+                else { if (useq) backward_lone<false, true>(a1, a2, fail, dt); else backward_lone<false, false>(a1, a2, fail, dt); }
               }
               lone_leave(ctx);
               if (bwrow) {
@@ -2335,11 +2411,16 @@ struct Solver {
               double b1, b2;
               bool bt;
               const LoneCtx sh = shadow_enter(bwrow);
+              // the Qz form of the pass: every row that takes part holds a trajectory a rollout has just produced
+              bool useq = false;
+              if constexpr (!CONES) useq = (P.useqz != 0) && !with_rho && (P.N <= ASET_MAXN) && !wave_any(bwrow && (rs->qvalid == 0));
               if (o.strict) {
                 if (with_rho) backward<true, true>(b1, b2, fail, bt, bwrow);
+                else if constexpr (!CONES) { if (useq) backward<false, true, true>(b1, b2, fail, bt, bwrow); else backward<false, true>(b1, b2, fail, bt, bwrow); }
                 else backward<false, true>(b1, b2, fail, bt, bwrow);
               } else {
                 if (with_rho) backward<true, false>(b1, b2, fail, bt, bwrow);
+                else if constexpr (!CONES) { if (useq) backward<false, false, true>(b1, b2, fail, bt, bwrow); else backward<false, false>(b1, b2, fail, bt, bwrow); }
                 else backward<false, false>(b1, b2, fail, bt, bwrow);
               }
               lone_leave(sh);

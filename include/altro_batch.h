@@ -357,7 +357,7 @@ int32_t altro_batch_get_initial_state(altro_handle* h, double* x0);
  * environment; a test or a measuring tool that wants one of the kernels' scheduling features off -- to show that it
  * changes no result, or to time it -- says so here.  h == NULL: for the handles THIS THREAD creates afterwards;
  * otherwise for that handle, from its next launch on.  Keys (value 0 restores the default):
- *   "no_lone", "no_shadow", "no_resync", "no_group", "no_reuse"   one scheduling feature of the 16-lane kernels off
+ *   "no_lone", "no_shadow", "no_resync", "no_group", "no_reuse", "no_qz_pass"   one scheduling feature of the 16-lane kernels off
  *   "group_mode" 0..4, "group_max_steps", "trace_wave"              slot order of a grouped launch / diagnostic builds
  *   "force_wide", "wide_compact", "wide_coop", "wide_static_mask"   read at altro_batch_create: NULL handle only
  *   "keep_gains"   the setters stop dropping the stored gains (the product then returns results from STALE gains: it

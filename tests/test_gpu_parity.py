@@ -1390,8 +1390,9 @@ def test_gain_reuse_is_dropped_by_every_setter_the_gains_depend_on(oracle, n, m,
 
 def test_scheduling_switches_do_not_change_results(monkeypatch):
     """Grouping the instances of a fused launch by their expected backward passes (ALTRO_NO_GROUP), keeping the rows of a
-    wave in step (ALTRO_NO_RESYNC), the lone-row pass (ALTRO_NO_LONE) and idle rows shadowing a busy one (ALTRO_NO_SHADOW) decide
-    WHEN, in WHICH wave and on whose operands a row idles, never what it computes: every output is the same bit for bit.  Gain reuse (ALTRO_NO_REUSE) changes the arithmetic of an
+    wave in step (ALTRO_NO_RESYNC), the lone-row pass (ALTRO_NO_LONE), idle rows shadowing a busy one (ALTRO_NO_SHADOW) and the backward
+    pass reading its cost / box expansion back from the plane the rollout left (ALTRO_NO_QZ_PASS) decide
+    WHEN, in WHICH wave, on whose operands and from which copy of the same numbers a row works, never what it computes: every output is the same bit for bit.  Gain reuse (ALTRO_NO_REUSE) changes the arithmetic of an
     iteration (first-order recursion with the stored gains instead of a backward pass): same statuses and iteration
     counts, trajectories equal to 1e-12."""
     B, S = 150, 14
@@ -1408,7 +1409,7 @@ def test_scheduling_switches_do_not_change_results(monkeypatch):
     a = run()
     assert int(altro.reuse_counter(a.solver).sum()) > 0
     Xa, Ua, La, sa = altro.states(a.solver), altro.controls(a.solver), altro.get_duals(a.solver), altro.stats(a.solver)
-    for var in ("ALTRO_NO_GROUP", "ALTRO_NO_RESYNC", "ALTRO_NO_LONE", "ALTRO_NO_SHADOW"):
+    for var in ("ALTRO_NO_GROUP", "ALTRO_NO_RESYNC", "ALTRO_NO_LONE", "ALTRO_NO_SHADOW", "ALTRO_NO_QZ_PASS"):
         monkeypatch.setenv(var, "1")
         b = run()
         monkeypatch.delenv(var)
