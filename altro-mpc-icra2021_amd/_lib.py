@@ -66,7 +66,7 @@ class AltroError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Generate the DPP block include and compile the HIP library for gfx950, in tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "pn_polish.h", "gen_dpp_blocks.py")]
+    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "pn_polish.h", "pn_wide.h", "gen_dpp_blocks.py")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "altro_batch.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -157,7 +157,7 @@ def lib():
 # `ALTRO_NO_LONE=1 python tools/...` and pytest's monkeypatch.setenv keep working.  (variable, key, default, negate)
 DEBUG_ENV = [
     ("ALTRO_NO_LONE", "no_lone", 0), ("ALTRO_NO_SHADOW", "no_shadow", 0), ("ALTRO_NO_RESYNC", "no_resync", 0),
-    ("ALTRO_NO_GROUP", "no_group", 0), ("ALTRO_NO_REUSE", "no_reuse", 0), ("ALTRO_NO_QZ_PASS", "no_qz_pass", 0), ("ALTRO_GROUP_MAX_STEPS", "group_max_steps", 32),
+    ("ALTRO_NO_GROUP", "no_group", 0), ("ALTRO_NO_REUSE", "no_reuse", 0), ("ALTRO_NO_QZ_PASS", "no_qz_pass", 0), ("ALTRO_NO_MATE_RANK", "no_mate_rank", 0), ("ALTRO_GROUP_MAX_STEPS", "group_max_steps", 32),
     ("ALTRO_DEBUG_TRACE_WAVE", "trace_wave", -1), ("ALTRO_FORCE_WIDE", "force_wide", 0),
     ("ALTRO_WIDE_COMPACT", "wide_compact", -1), ("ALTRO_WIDE_COOP", "wide_coop", -1),
     ("ALTRO_WIDE_STATIC_MASK", "wide_static_mask", -1), ("ALTRO_DEBUG_KEEP_GAINS", "keep_gains", 0),

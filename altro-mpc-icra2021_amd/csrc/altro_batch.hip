@@ -28,7 +28,7 @@ static thread_local std::string g_create_err;
 // a measuring tool that wants a scheduling feature off says so through the entry point -- with a null handle for the
 // handles this thread creates afterwards, with a handle for that handle.
 struct DebugSwitches {
-  int lone = 1, shadow = 1, resync = 1, reuse = 1, useqz = 1;
+  int lone = 1, shadow = 1, resync = 1, reuse = 1, useqz = 1, mate = 1;
   int group = 1;             // 0 off, 1 sorted, 2-4: other slot orders (k_group_rank)
   int group_max_steps = 32;
   int trace_wave = -1;       // -DALTRO_PHASE_STAMPS builds
@@ -83,6 +83,8 @@ struct altro_handle {
   int group = 1;                           // "no_group": identity; "group_mode": other slot orders
   int dbg_wave = -1;                       // "trace_wave" (diagnostic builds only)
   int resync = 1;                          // "no_resync": rows never wait for their wave-mates
+  int mate = 1;                            // "no_mate_rank": issue priority from the row's own state only, not from its SIMD mates'
+  unsigned* simd_tab = nullptr;            // [65536][16], zero between launches
   int *iters = nullptr, *iters_outer = nullptr, *status = nullptr;
   double *cost = nullptr, *cmax = nullptr, *Jtrace = nullptr, *ctrace = nullptr, *atrace = nullptr;
   double* stage = nullptr;  // device staging buffer for host<->device layout conversion
@@ -474,6 +476,7 @@ static int launch_solve(altro_handle* h, int first_step, int nsteps, int prepare
   p.iters = h->iters; p.iters_outer = h->iters_outer; p.status = h->status;
   p.cost = h->cost; p.cmax = h->cmax; p.Jtrace = h->Jtrace; p.ctrace = h->ctrace; p.atrace = h->atrace;
   p.n_backward = h->n_backward; p.n_rollout = h->n_rollout; p.wave_cycles = h->wave_cycles;
+  p.simd_tab = h->mate ? h->simd_tab : nullptr;
   p.n_solves = h->n_solves; p.n_iters = h->n_iters; p.n_ok = h->n_ok; p.n_trials = h->n_trials;
   p.n_gconf = h->n_gconf; p.dzero = h->dzero;
   p.o = h->o;
@@ -596,12 +599,13 @@ int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value) {
     }
     DebugSwitches tmp;
     DebugSwitches& d = h ? tmp : g_dbg;
-    if (h) { tmp.lone = h->lone; tmp.useqz = h->useqz; tmp.shadow = h->shadow; tmp.resync = h->resync; tmp.reuse = h->reuse; tmp.group = h->group;
+    if (h) { tmp.mate = h->mate; tmp.lone = h->lone; tmp.useqz = h->useqz; tmp.shadow = h->shadow; tmp.resync = h->resync; tmp.reuse = h->reuse; tmp.group = h->group;
              tmp.group_max_steps = h->group_max_steps; tmp.trace_wave = h->dbg_wave; }
     if (k == "no_lone") d.lone = value ? 0 : 1;
     else if (k == "no_qz_pass") d.useqz = value ? 0 : 1;
     else if (k == "no_shadow") d.shadow = value ? 0 : 1;
     else if (k == "no_resync") d.resync = value ? 0 : 1;
+    else if (k == "no_mate_rank") d.mate = value ? 0 : 1;
     else if (k == "no_reuse") d.reuse = value ? 0 : 1;
     else if (k == "no_group") d.group = value ? 0 : 1;
     else if (k == "group_mode") { if (value < 0 || value > 4) return bad(ALTRO_ERR_INVALID_ARG, "group_mode is 0..4"); d.group = value; }
@@ -610,6 +614,7 @@ int32_t altro_debug_set(altro_handle* h, const char* key, int32_t value) {
     else return bad(ALTRO_ERR_INVALID_ARG, "unknown switch");
     if (h && !h->wide) {
       const bool reuse_changed = h->reuse != tmp.reuse;
+      h->mate = tmp.mate;
       h->lone = tmp.lone; h->useqz = tmp.useqz; h->shadow = tmp.shadow; h->resync = tmp.resync; h->reuse = tmp.reuse; h->group = tmp.group;
       h->group_max_steps = tmp.group_max_steps; h->dbg_wave = tmp.trace_wave;
       if (reuse_changed) { HIPCHK(h, hipSetDevice(h->device)); return drop_gains(h); }
@@ -719,6 +724,7 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     h->d = *dims;
     if (opts) h->o = *opts; else altro_default_opts(&h->o);
     h->device = device;
+    h->mate = g_dbg.mate;
     h->lone = g_dbg.lone; h->useqz = g_dbg.useqz; h->shadow = g_dbg.shadow; h->resync = g_dbg.resync; h->reuse = g_dbg.reuse; h->group = g_dbg.group;
     h->group_max_steps = g_dbg.group_max_steps; h->dbg_wave = g_dbg.trace_wave; h->debug_keep_gains = g_dbg.keep_gains != 0;
     h->Bp = (dims->batch + IPW - 1) / IPW * IPW;
@@ -818,6 +824,8 @@ int32_t altro_batch_create(const altro_dims* dims, const altro_opts* opts, int32
     CCHK(hipMalloc(&h->n_backward, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_rollout, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->wave_cycles, (Bp * 4 + 4096) * sizeof(long long)));
+    CCHK(hipMalloc(&h->simd_tab, (size_t)65536 * 16 * sizeof(unsigned)));
+    CCHK(hipMemsetAsync(h->simd_tab, 0, (size_t)65536 * 16 * sizeof(unsigned), h->stream));
     CCHK(hipMalloc(&h->n_solves, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_iters, Bp * sizeof(long long)));
     CCHK(hipMalloc(&h->n_ok, Bp * sizeof(long long)));
@@ -872,7 +880,7 @@ static void free_dpp_backend(altro_handle* h) {
                    (void**)&h->cmeta, (void**)&h->ckn, (void**)&h->Lc, (void**)&h->lanebuf, (void**)&h->noise_w, (void**)&h->noise_grp, (void**)&h->mu,
                    (void**)&h->KD, (void**)&h->noise, (void**)&h->cur, (void**)&h->iters, (void**)&h->iters_outer, (void**)&h->status,
                    (void**)&h->cost, (void**)&h->cmax, (void**)&h->Jtrace, (void**)&h->ctrace, (void**)&h->atrace, (void**)&h->stage,
-                   (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->n_solves, (void**)&h->n_iters,
+                   (void**)&h->n_backward, (void**)&h->n_rollout, (void**)&h->wave_cycles, (void**)&h->simd_tab, (void**)&h->n_solves, (void**)&h->n_iters,
                    (void**)&h->n_ok, (void**)&h->n_trials, (void**)&h->Zsave, (void**)&h->n_gconf, (void**)&h->dzero, (void**)&h->Qz,
                    (void**)&h->Dff, (void**)&h->ahash, (void**)&h->kmu, (void**)&h->n_fo, (void**)&h->perm, (void**)&h->gscore,
                    (void**)&h->pn_ran, (void**)&h->pn_failed, (void**)&h->pn_res, (void**)&h->pn_dfail, (void**)&h->pn_dres0, (void**)&h->pn_dres, (void**)&h->pnE, (void**)&h->pndv, (void**)&h->pnLd, (void**)&h->pnLo,
@@ -1361,17 +1369,26 @@ static int enqueue_solve(altro_handle* h, int first_step, int nsteps) {
   const int last_kref = nsteps > 0 ? first_step + nsteps : h->kref;
   if (last_kref + h->d.N > h->Nt) FAIL(h, ALTRO_ERR_STATE, "reference window runs past the end of the stored trajectory");
   // everything that can refuse the launch comes before it takes a slot of the timing ring
-  if (h->o.projected_newton && nsteps > 0)
-    FAIL(h, ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
-                                   "(every MPC script of the reference sets projected_newton = false)");
   if (h->o.projected_newton && (rc = prepare_polish(h))) return rc;
   if (!supported_dims(h->d.n, h->d.m)) FAIL(h, ALTRO_ERR_UNSUPPORTED, "no kernel built for this (n, m)");
   hipEvent_t h0, h1;
   HIPCHK(h, h->ring.next(&h0, &h1));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   HIPCHK(h, hipEventRecord(h0, h->stream));
-  rc = launch_solve(h, first_step, nsteps);
-  if (!rc && h->o.projected_newton) rc = launch_polish(h);
+  if (h->o.projected_newton && nsteps > 0) {
+    // solve!(::ALTROSolver) ends with the polish, and the next step's shift starts from what it left: the steps of a fused
+    // launch run as nsteps pairs of (one-step solve kernel, polish kernel) on the stream, the polish over the step's window
+    const int kref0 = h->kref;
+    for (int s = 0; s < nsteps && !rc; ++s) {
+      rc = launch_solve(h, first_step + s, 1);
+      h->kref = first_step + s + 1;
+      if (!rc) rc = launch_polish(h);
+    }
+    if (rc) h->kref = kref0;
+  } else {
+    rc = launch_solve(h, first_step, nsteps);
+    if (!rc && h->o.projected_newton) rc = launch_polish(h);
+  }
   // (a launch that failed after all -- a HIP error -- still closes its slot: every slot handed out has both events)
   HIPCHK(h, hipEventRecord(h1, h->stream));
   if (rc) return rc;

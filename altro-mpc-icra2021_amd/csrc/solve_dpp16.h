@@ -183,6 +183,7 @@ struct SolveParams {
   long long* n_ok;       // [Bp] solves that ended SOLVE_SUCCEEDED
   long long* n_gconf;    // [Bp] iterations confirmed by the costate sweep instead of a backward pass
   int* dzero;            // [Bp] 1: the feedforward terms of the last solve's last iteration are zero (costate-confirmed)
+  unsigned* simd_tab;    // [65536][16] or null: per physical SIMD and wave slot, the work a resident wave has left (see Solver::mate_rank)
   long long* wave_cycles; // [Bp/4][16] shader cycles of the last launch, per wave (diagnostic):
                           // total, backward, closed rollouts, open rollouts, todorov, dual update,
                           // streaming line-search sweeps
@@ -406,6 +407,8 @@ struct Solver {
   double* sm;    // this row's 16 x 17 transpose tile (LDS)
   bool hard_wave = false;  // wave-uniform: a row of this wave is in a hard solve (see ALTRO_PRIO_HARD)
   bool heavy_half = false; // wave-uniform: upper half of a grouped launch (see ALTRO_PRIO_HEAVY)
+  unsigned* simd_row = nullptr;  // this wave's SIMD in P.simd_tab (16 wave slots), or null
+  unsigned wave_slot = 0;
   int turns = 0;           // turns of the wave loop so far
   int n_lone = 0;          // backward passes of this launch that ran as backward_lone (diagnostic, wave_cycles[7])
   ASet* ah;    // this lane's active set of the backward pass that left the gains in KD (LDS; kept in P.ahash between launches)
@@ -434,6 +437,14 @@ struct Solver {
     inst = blockIdx.x * IPW + (lane >> 4);
     if (P.perm != nullptr) inst = P.perm[inst];
     heavy_half = (P.perm != nullptr) && (2u * blockIdx.x >= gridDim.x);
+    if (P.simd_tab != nullptr) {
+      // HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0
+      const unsigned a = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+      const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 0xf;
+      const unsigned key = (x << 12) | (((a >> 13) & 7) << 9) | (((a >> 12) & 1) << 8) | (((a >> 8) & 15) << 2) | ((a >> 4) & 3);
+      simd_row = P.simd_tab + (size_t)key * 16;
+      wave_slot = a & 15;
+    }
     rs = rows + (lane >> 4);
     sm = tiles + (lane >> 4) * (LW * (LW + 1));
     is_x = j < NX;
@@ -537,6 +548,24 @@ struct Solver {
   }
   static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
   static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+  // Who of the waves on this SIMD has more work left.  The launch ends with its slowest wave, and while two waves share a
+  // SIMD the VALU is issue-bound: the one that issues first runs at the speed it would have alone, the other
+  // gets the slots that are left.  Age decides between equal priorities, and age knows nothing of the work: so every turn a
+  // wave publishes an estimate of what it has left -- the steps to go at the turns per step it needed so far -- in the slot of
+  // its SIMD (HW_ID), reads its mates' and takes the high priorities if none of them has more.
+  __device__ __forceinline__ bool mate_rank(int steps_left, int steps_done) const {
+    // (measured over twelve 20-step windows, two boxes: 9.27 -> 9.00 ms and 9.29 -> 9.03 ms against the row's own state alone;
+    //  the steps left alone as the estimate, and the priorities 0/0 or 0/1 against 3/3 instead of 0/1 against 2/3: the same)
+    const unsigned mine = 1u + (unsigned)(steps_left * (turns + 1) * 16) / (unsigned)(steps_done + 1);
+    if (lane == 0) __hip_atomic_store(simd_row + wave_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned other = 0u;
+    if (lane < 16 && (unsigned)lane != wave_slot) other = __hip_atomic_load(simd_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return !wave_any(other > mine);
+  }
+  __device__ __forceinline__ void mate_leave() const {
+    if (simd_row != nullptr && lane == 0) __hip_atomic_store(simd_row + wave_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   __device__ __forceinline__ void prio_serial() const {
     if (ALTRO_PRIO_HARD > 0 && hard_wave) __builtin_amdgcn_s_setprio(ALTRO_PRIO_HARD < 3 ? ALTRO_PRIO_HARD + 1 : 3);
@@ -2330,6 +2359,7 @@ struct Solver {
         int ms = r0[0].step;
         sfor<1, IPW>([&](auto q) { ms = imin(ms, r0[decltype(q)::value].step); });
         hard_wave = wave_any((rs->phase == PH_ITER) && (rs->iters >= 2)) || (ALTRO_PRIO_LAG > 0 && turns - 2 * ms >= ALTRO_PRIO_LAG + 2);
+        if (simd_row != nullptr && mpc) hard_wave = mate_rank(nsteps - imin(ms, nsteps), ms);
       }
       prio_base();
       {
@@ -2729,6 +2759,7 @@ __global__ void __launch_bounds__(64, (CONES || NU > 4) ? 1 : ALTRO_WAVES_PER_SI
   Solver<NX, NU, CONES> s(p, rows, tiles, hashes);
   ALTRO_STAMP(s.t_start = t0;)
   s.run(p.nsteps > 0, p.first_step, p.nsteps);
+  s.mate_leave();
   s.finish();
   const long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) {

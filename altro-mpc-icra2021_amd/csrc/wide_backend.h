@@ -557,18 +557,29 @@ struct WideBackend {
     if (mpc && ltv && dyn_step_stride == 0)
       WFAIL(ALTRO_ERR_UNSUPPORTED, "the device MPC loop over per-knot dynamics needs their table for every step: altro_mpc_set_dynamics_track");
     if (!dyn_covers(last_kref)) WFAIL(ALTRO_ERR_STATE, "the dynamics track ends before the last step's window");
-    if (o.projected_newton && mpc)
-      WFAIL(ALTRO_ERR_UNSUPPORTED, "projected_newton with the device-resident MPC loop: the polish runs after plain solves "
-                                   "(every MPC script of the reference sets projected_newton = false)");
     if (o.projected_newton && (rc = polish_prepare())) return rc;
     hipEvent_t h0, h1;
     WCHK(ring.next(&h0, &h1));
     WCHK(hipEventRecord(ev0, stream));
     WCHK(hipEventRecord(h0, stream));
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
-    rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
-    if (rc) err = "launch of the solve kernel failed";
-    if (!rc && o.projected_newton) rc = polish_launch();
+    if (o.projected_newton && mpc) {
+      // the steps of a fused launch as nsteps pairs of (one-step solve kernel, polish kernel): the next step's shift starts
+      // from the polished trajectory and the projected multipliers, as after solve!(::ALTROSolver)
+      const int kref0 = kref;
+      for (int s = 0; s < nsteps && !rc; ++s) {
+        hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step + s, 1);
+        rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
+        if (rc) err = "launch of the solve kernel failed";
+        kref = first_step + s + 1;
+        if (!rc) rc = polish_launch();
+      }
+      if (rc) kref = kref0;
+    } else {
+      hipLaunchKernelGGL(wide_kernel_for(d.n, d.m), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
+      rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
+      if (rc) err = "launch of the solve kernel failed";
+      if (!rc && o.projected_newton) rc = polish_launch();
+    }
     gains_valid = true;  // (until a setter changes something the stored gains depend on)
     WCHK(hipEventRecord(h1, stream));   // (every slot of the ring handed out has both events)
     if (rc) return rc;

@@ -135,7 +135,9 @@ typedef struct altro_opts {
    * projected_newton = false (eleven occurrences), and the ccall shim passes the Julia-side value explicitly.  1: plain
    * solves (altro_batch_solve) run the polish after the AL kernel -- csrc/pn_polish.h on the 16-lane backend, csrc/pn_wide.h
    * on the one-wave-per-instance backend (any n <= 64, m <= 32, per-knot dynamics) -- primal projection first, then
-   * Altro's multiplier projection (altro_batch_get_polish_dual_residuals); the device-resident MPC loop refuses it.
+   * Altro's multiplier projection (altro_batch_get_polish_dual_residuals).  Inside the device-resident MPC loop
+   * (altro_mpc_step_async / altro_mpc_run_async) every step is then a one-step solve kernel followed by the polish kernel:
+   * the next step shifts the polished trajectory and the projected multipliers.
    * PARITY UNPINNED: the reference stores no polished trajectory. */
   int32_t projected_newton;
   double projected_newton_tolerance;   /* 1e-3 */
@@ -357,7 +359,7 @@ int32_t altro_batch_get_initial_state(altro_handle* h, double* x0);
  * environment; a test or a measuring tool that wants one of the kernels' scheduling features off -- to show that it
  * changes no result, or to time it -- says so here.  h == NULL: for the handles THIS THREAD creates afterwards;
  * otherwise for that handle, from its next launch on.  Keys (value 0 restores the default):
- *   "no_lone", "no_shadow", "no_resync", "no_group", "no_reuse", "no_qz_pass"   one scheduling feature of the 16-lane kernels off
+ *   "no_lone", "no_shadow", "no_resync", "no_group", "no_reuse", "no_qz_pass", "no_mate_rank"   one scheduling feature of the 16-lane kernels off
  *   "group_mode" 0..4, "group_max_steps", "trace_wave"              slot order of a grouped launch / diagnostic builds
  *   "force_wide", "wide_compact", "wide_coop", "wide_static_mask"   read at altro_batch_create: NULL handle only
  *   "keep_gains"   the setters stop dropping the stored gains (the product then returns results from STALE gains: it

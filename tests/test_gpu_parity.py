@@ -1391,7 +1391,8 @@ def test_gain_reuse_is_dropped_by_every_setter_the_gains_depend_on(oracle, n, m,
 def test_scheduling_switches_do_not_change_results(monkeypatch):
     """Grouping the instances of a fused launch by their expected backward passes (ALTRO_NO_GROUP), keeping the rows of a
     wave in step (ALTRO_NO_RESYNC), the lone-row pass (ALTRO_NO_LONE), idle rows shadowing a busy one (ALTRO_NO_SHADOW) and the backward
-    pass reading its cost / box expansion back from the plane the rollout left (ALTRO_NO_QZ_PASS) decide
+    pass reading its cost / box expansion back from the plane the rollout left (ALTRO_NO_QZ_PASS), issue priority for the wave of a
+    SIMD that has more work left (ALTRO_NO_MATE_RANK) decide
     WHEN, in WHICH wave, on whose operands and from which copy of the same numbers a row works, never what it computes: every output is the same bit for bit.  Gain reuse (ALTRO_NO_REUSE) changes the arithmetic of an
     iteration (first-order recursion with the stored gains instead of a backward pass): same statuses and iteration
     counts, trajectories equal to 1e-12."""
@@ -1409,7 +1410,7 @@ def test_scheduling_switches_do_not_change_results(monkeypatch):
     a = run()
     assert int(altro.reuse_counter(a.solver).sum()) > 0
     Xa, Ua, La, sa = altro.states(a.solver), altro.controls(a.solver), altro.get_duals(a.solver), altro.stats(a.solver)
-    for var in ("ALTRO_NO_GROUP", "ALTRO_NO_RESYNC", "ALTRO_NO_LONE", "ALTRO_NO_SHADOW", "ALTRO_NO_QZ_PASS"):
+    for var in ("ALTRO_NO_GROUP", "ALTRO_NO_RESYNC", "ALTRO_NO_LONE", "ALTRO_NO_SHADOW", "ALTRO_NO_QZ_PASS", "ALTRO_NO_MATE_RANK"):
         monkeypatch.setenv(var, "1")
         b = run()
         monkeypatch.delenv(var)
@@ -1716,11 +1717,48 @@ def test_projected_newton_polish_matches_oracle(oracle):
         assert rel_err(X[b], o.states()) <= 1e-5 and rel_err(U[b], o.controls()) <= 1e-5
         assert int(dfail[b]) == so.pn_dual_failed
         assert abs(d0[b] - so.pn_dual_residual0) <= 1e-4 * max(1.0, so.pn_dual_residual0) and abs(d1[b] - so.pn_dual_residual) <= 1e-4 * max(1.0, so.pn_dual_residual0)
-    # the device-resident MPC loop refuses the option
-    with pytest.raises(altro.AltroError):
-        mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(**opts))
-        mp.initial_solve()
-        mp.step(0)
+
+
+@pytest.mark.parametrize("n,m,N", [(12, 4, 21), (20, 4, 21)])
+def test_projected_newton_polish_inside_the_mpc_loop(oracle, n, m, N):
+    """solve!(::ALTROSolver) ends with the polish (Altro's default), so an MPC loop with projected_newton = 1 shifts the
+    POLISHED trajectory and the PROJECTED multipliers into the next step.  Both backends ((12, 4): 16-lane, (20, 4): one wave
+    per instance) run the steps of a fused launch as pairs of (one-step solve kernel, polish kernel); against the oracle's loop
+    step by step, and the fused launch against single steps bit for bit."""
+    B, S = 5, 6
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=87)
+    pb.u_bnd = 1.0                                   # the track was generated with |u| <= 3: controls saturate in every solve, the AL stage ends above 1e-8
+    opts = dict(REF_OPTS, constraint_tolerance=1e-8, projected_newton=1)
+    mp = altro.mpc.BatchMPC(pb, altro.SolverOptions(**opts))
+    mp.initial_solve()
+    orcs = [make_oracle(oracle, pb, b, opts=opts) for b in range(B)]
+    for o in orcs:
+        o.solve()
+    nran = 0
+    for i in range(S):
+        mp.step(i)
+        st, X, U, L = altro.stats(mp.solver), altro.states(mp.solver), altro.controls(mp.solver), altro.get_duals(mp.solver)
+        ran, failed, res = altro.polish_stats(mp.solver)
+        x0g = mp.x0()
+        assert not failed.any()
+        for b in range(B):
+            x0 = mpc_update(orcs[b], pb, b, i)
+            assert np.abs(x0 - x0g[b]).max() <= 1e-9 * max(1.0, np.abs(x0).max())
+            so = orcs[b].solve()
+            assert int(st.status[b]) == so.status == 1 and int(st.iterations[b]) == so.iterations and int(ran[b]) == so.pn_ran, (i, b)
+            assert rel_err(X[b], orcs[b].states()) <= RTOL and rel_err(U[b], orcs[b].controls()) <= RTOL, (i, b)
+            assert st.c_max[b] < 1e-8
+            lo = orcs[b].duals(0).reshape(N - 1, 2, n + m)
+            assert np.abs(L[b][:N - 1] - lo).max() <= 1e-6 * max(1.0, np.abs(lo).max()), (i, b)
+            nran += so.pn_ran
+    assert nran >= B * S - 2    # the polish ran in (nearly) every solve of the loop
+    # K fused steps = K single steps
+    mf = altro.mpc.BatchMPC(pb, altro.SolverOptions(**opts))
+    mf.initial_solve()
+    mf.run_async(S, first=0)
+    mf.synchronize()
+    assert np.array_equal(altro.states(mf.solver), X) and np.array_equal(altro.controls(mf.solver), U)
+    assert np.array_equal(altro.get_duals(mf.solver), L) and np.array_equal(mf.x0(), x0g)
 
 
 def test_projected_newton_polish_on_the_one_wave_per_instance_backend(oracle, monkeypatch):
