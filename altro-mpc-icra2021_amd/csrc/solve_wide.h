@@ -304,9 +304,39 @@ __device__ __forceinline__ long long wstamp() {
 // dimensions of the LDS carve-up are then compile-time constants: the tile loops of the products collapse into
 // straight-line MFMA chains with immediate LDS offsets, and a few dozen wave-uniform values leave the SGPR file
 // (the generic kernel spills SGPRs into VGPR lanes -- ~500 v_readlane per knot).
+// A register budget per phase (round 4).  The solver below used to be ONE inlined body of ~40 k instructions: the register
+// allocation of such a function is global, and with more than 512 values alive somewhere in it the allocator spilled
+// 220-670 VGPRs and over 1000 SGPRs -- into the hot loops of phases that need a fraction of the file on their own
+// (loop-invariant columns of A reloaded from scratch in front of every FMA, `s_waitcnt vmcnt(0)` behind each).  The phases
+// are now real functions (wide_phase<MC, SM, OP>, noinline): each builds its own Solver from the kernel's arguments (the
+// pointers and strides are recomputed: ~100 instructions per call) and gets the few values of the solver that change
+// (PhIn) as arguments; what it produces comes back in PhOut.  LDS contents (resident dynamics, parked blocks) and the
+// arrays in HBM carry everything else.  ALTRO_WIDE_SPLIT=0 compiles the old single body (same arithmetic, same results).
+#ifndef ALTRO_WIDE_SPLIT
+#define ALTRO_WIDE_SPLIT 1
+#endif
+enum { PH_ROLL_OPEN = 0, PH_ROLL, PH_BACKWARD, PH_ADJ_FULL, PH_ADJ_CONF, PH_GRAD_ADJ_ROW, PH_DUAL, PH_SHIFT, PH_PLANT };
+struct PhIn {
+  int cur, kref, i0, flags;
+  double mu, rho, a;
+  unsigned long long h;
+};
+struct PhOut {
+  double a, b;
+  unsigned long long h;
+  int flags;
+#ifdef ALTRO_WIDE_STAMPS
+  long long t[5];
+#endif
+};
+template <int MC, bool SM, int OP>
+__device__ PhOut wide_phase(unsigned long long kp, PhIn in);
+struct Resume {};
+
 template <int MC, bool SM>
 struct Solver {
   const Params& P;
+  unsigned long long kp = 0ull;  // the kernel's argument segment (what a phase function rebuilds P from)
   int T;  // lane index; made opaque again at the start of every phase (phase_begin)
   const int inst, n, m, N, np, mp, nz, nzp, Pn, Pp;
   const Lds ly;
@@ -365,6 +395,15 @@ struct Solver {
   __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
         nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
+    init(lds, true);
+  }
+  // a phase function's view of the same instance: same pointers, LDS as the kernel left it
+  __device__ __forceinline__ Solver(const Params& p, double* lds, Resume)
+      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
+        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
+    init(lds, false);
+  }
+  __device__ __forceinline__ void init(double* lds, bool fresh) {
     lds_base = lds;
     G = lds + ly.G; S = lds + ly.S; W = lds + ly.W; Hux = lds + ly.Hux; Kl = lds + ly.Kl; Huu = lds + ly.Huu;
     Ac = lds + ly.Ac; DA = lds + ly.DA;
@@ -385,10 +424,88 @@ struct Solver {
     AconTi = P.AconT + b * P.con_istride;
     bconi = P.bcon + b * P.bcon_istride;
     Xri = P.Xref + b * P.Nt * n; Uri = P.Uref + b * (P.Nt - 1) * m;
-    for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
+    if (fresh)
+      for (int e = T; e < ly.total; e += 64) lds[e] = 0.0;
     if (T < n) { cwx = P.wd[T]; cwfx = P.wf[T]; cxmax = P.zmax[T]; cxmin = P.zmin[T]; }
     if (T < m) { cwu = P.wd[n + T]; cumax = P.zmax[n + T]; cumin = P.zmin[n + T]; }
-    block_sync();
+    if (fresh) block_sync();
+  }
+
+  struct RollOut {
+    double J, cmax;
+    bool limit;
+    bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
+    bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
+    unsigned long long qh;  // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
+  };
+
+  // ---- the phases as calls (ALTRO_WIDE_SPLIT) or inline ----
+  __device__ __forceinline__ PhIn ph_in(double a = 0.0, int i0 = 0) const {
+    PhIn in;
+    in.cur = cur; in.kref = kref; in.i0 = i0; in.flags = dtiny ? 1 : 0;
+    in.mu = mu; in.rho = rho; in.a = a; in.h = bw_hash;
+    return in;
+  }
+  __device__ __forceinline__ void ph_stamps(const PhOut& o) {
+#ifdef ALTRO_WIDE_STAMPS
+    t_gemm += o.t[0]; t_a += o.t[1]; t_b += o.t[2]; t_c += o.t[3]; t_d += o.t[4];
+#else
+    (void)o;
+#endif
+  }
+  __device__ __forceinline__ RollOut do_rollout(bool open, double alpha) {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) {
+      const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL>(kp, ph_in(alpha));
+      RollOut r;
+      r.J = o.a; r.cmax = o.b; r.qh = o.h;
+      r.limit = (o.flags & 1) != 0; r.unchanged = (o.flags & 2) != 0; r.tiny = (o.flags & 4) != 0;
+      return r;
+    } else {
+      return rollout(open, alpha);
+    }
+  }
+  __device__ __forceinline__ bool do_backward(double& dV1, double& dV2) {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) {
+      const PhOut o = wide_phase<MC, SM, PH_BACKWARD>(kp, ph_in());
+      dV1 = o.a; dV2 = o.b; bw_hash = o.h; dtiny = (o.flags & 2) != 0;
+      ph_stamps(o);
+      return (o.flags & 1) != 0;
+    } else {
+      return backward(dV1, dV2);
+    }
+  }
+  __device__ __forceinline__ bool do_adjoint_lds(bool full, double& dV1, double& dV2) {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) {
+      const PhOut o = full ? wide_phase<MC, SM, PH_ADJ_FULL>(kp, ph_in()) : wide_phase<MC, SM, PH_ADJ_CONF>(kp, ph_in());
+      dV1 = o.a; dV2 = o.b;
+      return (o.flags & 1) != 0;
+    } else {
+      return adjoint_lds(full, dV1, dV2);
+    }
+  }
+  __device__ __forceinline__ bool grad_adjoint_row() {
+    if constexpr (SM) {
+      if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
+      return P.ltv ? adjoint_row<true>() : adjoint_row<false>();
+    } else {
+      return false;
+    }
+  }
+  __device__ __forceinline__ bool do_grad_adjoint_row() {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) return (wide_phase<MC, SM, PH_GRAD_ADJ_ROW>(kp, ph_in()).flags & 1) != 0;
+    else return grad_adjoint_row();
+  }
+  __device__ __forceinline__ void do_dual_update() {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_DUAL>(kp, ph_in());
+    else dual_update();
+  }
+  __device__ __forceinline__ void do_shift() {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_SHIFT>(kp, ph_in());
+    else shift(true, true);
+  }
+  __device__ __forceinline__ void do_plant_step(int step) {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_PLANT>(kp, ph_in(0.0, step));
+    else plant_step(step);
   }
 
   // Everything lane-dependent that a phase needs (dozens of addresses and offsets per phase) is loop-invariant for
@@ -586,14 +703,6 @@ struct Solver {
       Ac[r * ly.ldg + c] = AconTi[((size_t)P.rowk0[r] * nz + j) * Pn + r];
     }
   }
-
-  struct RollOut {
-    double J, cmax;
-    bool limit;
-    bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
-    bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
-    unsigned long long qh;  // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
-  };
 
   // ---- second-order cone rows (oracle soc_project / con_cost / cost_expansion) -------------
   // value v and dual lam of the whole cone are exchanged through LDS (cvv, cll); every lane of the
@@ -2291,7 +2400,7 @@ struct Solver {
     drho = 0.0;
     dj_zero = 0;
     WSTAMP(const long long ts0 = wstamp();)
-    RollOut r0 = rollout(true, 0.0);
+    RollOut r0 = do_rollout(true, 0.0);
     WSTAMP(t_ro += wstamp() - ts0;)
     nro++;
     if (r0.limit) {
@@ -2324,7 +2433,7 @@ struct Solver {
         if (reuse_class && bw_ok && bw_plain && qvalid && rho == 0.0 && mu == bw_mu && !wave_any(q_hash != bw_hash)) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
-          dtiny = adjoint_lds(true, dV1, dV2);
+          dtiny = do_adjoint_lds(true, dV1, dV2);
           WSTAMP(t_td += wstamp() - ts;)
           swept = true;
           ngs++;
@@ -2345,10 +2454,9 @@ struct Solver {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
           if constexpr (SM) {
-            if (Pn > 0) grad_pass<true>(); else grad_pass<false>();
-            gconf = P.ltv ? adjoint_row<true>() : adjoint_row<false>();
+            gconf = do_grad_adjoint_row();
           } else {
-            gconf = adjoint_lds(false, dV1, dV2);
+            gconf = do_adjoint_lds(false, dV1, dV2);
           }
           WSTAMP(t_td += wstamp() - ts;)
           if (gconf) {
@@ -2363,7 +2471,7 @@ struct Solver {
       while (!gconf && !swept) {  // regularisation restarts
         const bool plain = rho == 0.0;
         WSTAMP(const long long ts = wstamp();)
-        const bool fail = backward(dV1, dV2);
+        const bool fail = do_backward(dV1, dV2);
         WSTAMP(t_bw += wstamp() - ts;)
         block_sync();  // phase end: gains written to global memory are read by other lanes in the rollout
         if (!fail) {
@@ -2410,7 +2518,7 @@ struct Solver {
           break;
         }
         WSTAMP(const long long ts = wstamp();)
-        const RollOut r = rollout(false, alpha);
+        const RollOut r = do_rollout(false, alpha);
         WSTAMP(t_ro += wstamp() - ts;)
         if (ls == 0) nro++; else ntr++;
         qh_acc = r.qh;  // (the last trial run is the accepted one, if any is)
@@ -2596,7 +2704,7 @@ struct Solver {
       if (cmax < o.constraint_tolerance || (o.kickout_max_penalty && mu >= o.penalty_max)) break;
       if (last) { status = ALTRO_MAX_ITERATIONS_OUTER; break; }
       WSTAMP(const long long tdu = wstamp();)
-      dual_update();
+      do_dual_update();
       WSTAMP(t_du += wstamp() - tdu;)
       mu = fmin(fmax(phi * mu, 0.0), o.penalty_max);
     }
@@ -2631,10 +2739,10 @@ struct Solver {
     for (int s = 0; s < steps; ++s) {
       if (mpc) {
         WSTAMP(const long long tsh = wstamp();)
-        plant_step(first_step + s);
+        do_plant_step(first_step + s);
         kref = first_step + s + 1;  // update_trajectory!(obj, Z_track, k_mpc)
         if (mpc == 2) break;        // altro_mpc_prepare_async: new x0 only, no shift, no solve
-        if (P.mpc_shift) shift(true, true);
+        if (P.mpc_shift) do_shift();
         WSTAMP(t_sh += wstamp() - tsh;)
       }
       solve_one();
@@ -2684,6 +2792,58 @@ struct Solver {
   }
 };
 
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// One phase of the solver as a function of its own (see PhIn above).  The arguments arrive in VGPRs: what is wave-uniform is
+// made scalar again first thing, so that addresses and loop bounds derived from it stay in the scalar unit.
+template <int MC, bool SM, int OP>
+__device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhIn in) {
+  extern __shared__ double lds[];
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kp), hi = __builtin_amdgcn_readfirstlane((unsigned)(kp >> 32));
+  typedef const __attribute__((address_space(4))) Params* KP;   // the kernel-argument segment: constant memory, scalar loads
+  const Params& P = *(const Params*)(KP)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+  Solver<MC, SM> s(P, lds, Resume{});
+  s.cur = __builtin_amdgcn_readfirstlane(in.cur);
+  s.kref = __builtin_amdgcn_readfirstlane(in.kref);
+  s.mu = uniform_f64(in.mu);
+  s.rho = uniform_f64(in.rho);
+  s.bw_hash = in.h;
+  s.dtiny = (__builtin_amdgcn_readfirstlane(in.flags) & 1) != 0;
+  PhOut o;
+  o.a = o.b = 0.0;
+  o.h = 0ull;
+  o.flags = 0;
+  if constexpr (OP == PH_ROLL_OPEN || OP == PH_ROLL) {
+    const typename Solver<MC, SM>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
+    o.a = r.J; o.b = r.cmax; o.h = r.qh;
+    o.flags = (r.limit ? 1 : 0) | (r.unchanged ? 2 : 0) | (r.tiny ? 4 : 0);
+  } else if constexpr (OP == PH_BACKWARD) {
+    double d1 = 0.0, d2 = 0.0;
+    const bool fail = s.backward(d1, d2);
+    o.a = d1; o.b = d2; o.h = s.bw_hash;
+    o.flags = (fail ? 1 : 0) | (s.dtiny ? 2 : 0);
+  } else if constexpr (OP == PH_ADJ_FULL || OP == PH_ADJ_CONF) {
+    double d1 = 0.0, d2 = 0.0;
+    const bool ok = s.adjoint_lds(OP == PH_ADJ_FULL, d1, d2);
+    o.a = d1; o.b = d2;
+    o.flags = ok ? 1 : 0;
+  } else if constexpr (OP == PH_GRAD_ADJ_ROW) {
+    o.flags = s.grad_adjoint_row() ? 1 : 0;
+  } else if constexpr (OP == PH_DUAL) {
+    s.dual_update();
+  } else if constexpr (OP == PH_SHIFT) {
+    s.shift(true, true);
+  } else if constexpr (OP == PH_PLANT) {
+    s.plant_step(__builtin_amdgcn_readfirstlane(in.i0));
+  }
+#ifdef ALTRO_WIDE_STAMPS
+  o.t[0] = s.t_gemm; o.t[1] = s.t_a; o.t[2] = s.t_b; o.t[3] = s.t_c; o.t[4] = s.t_d;
+#endif
+  return o;
+}
+
 // waves per SIMD the register allocator is held to, per control-size class
 #ifndef ALTRO_WIDE_WAVES_SM
 #define ALTRO_WIDE_WAVES_SM 1
@@ -2700,6 +2860,7 @@ __global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel
     return;
   }
   Solver<MC, SM> s(P, lds);
+  s.kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();   // P is the first argument: offset 0
   s.run(mpc, first_step, nsteps);
 }
 
