@@ -1160,6 +1160,9 @@ struct Solver {
     };
     // The per-lane operands are requested THREE knots ahead: a knot is ~1.5 k cycles of arithmetic, a round trip to
     // HBM ~4 k, and the wave has the SIMD to itself -- with one knot of lookahead every knot waited for memory.
+    // (Compile-time slots instead of the copy rotation below -- four knots per body -- were tried again in round 4 with the
+    // rollout a function of its own: the body of the quadruped's variant still needs 256 + 256 registers and 763 scratch
+    // operations, with or without a scheduling barrier per knot.)
     // The loop body is one basic block (no branch: hipcc waits vmcnt(0) after a join), so the waits are counted.
     lds_d* const park[2] = {(lds_d*)W, (lds_d*)Hux};
     lds_d* const kpark[2] = {(lds_d*)S, (lds_d*)Huu};
@@ -2845,10 +2848,14 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
 }
 
 // waves per SIMD the register allocator is held to, per control-size class
+// n, m <= 16 with m <= 8: two waves per SIMD (256 registers each).  With the phases as functions of their own the spills that
+// made this slower in round 3 stay out of the knot loops: n = 16, m = 4 at batch 8192: 97.7 -> 79.4 ms per 30 steps, (12, 6):
+// 136.9 -> 122.1, (16, 8): 144.9 -> 129.9; at batch 1024 (one wave per SIMD either way) the same speed.  m = 9..16 (the
+// quadruped): the triangle of factor_solve_lane<12> does not fit 256 registers, a wave is 2x slower there.
 #ifndef ALTRO_WIDE_WAVES_SM
-#define ALTRO_WIDE_WAVES_SM 1
+#define ALTRO_WIDE_WAVES_SM 2
 #endif
-constexpr int wide_waves(int MC, bool SM) { return SM ? ALTRO_WIDE_WAVES_SM : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
+constexpr int wide_waves(int MC, bool SM) { return SM ? (MC <= 8 ? ALTRO_WIDE_WAVES_SM : 1) : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
 
 // threads per block: the n, m <= 16 instantiations are always one wave; the others may be launched as a cooperative
 // block of four (wide_block_threads)

@@ -1,6 +1,6 @@
 """A/B of builds of the library (tools/build_ab.sh, -DALTRO_DEV_WIDE_KERNEL=...) on one-wave-per-instance workloads: kernel time
 of three 10-step windows and a checksum of the final states / controls / iteration counts (builds that only move code must agree
-bit for bit).  Usage: gpu_wide_ab.py quad|n16|n32|n64 tag=lib.so [tag=lib.so ...]"""
+bit for bit).  Usage: gpu_wide_ab.py quad|n16|n32|n64|n12m6 tag=lib.so [tag=lib.so ...]"""
 import sys, os, subprocess, hashlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
@@ -22,9 +22,11 @@ if len(sys.argv) == 3 and "=" not in sys.argv[2]:
         api.set_dynamics_track(mp.solver, A, Bm, d, step_stride=1)
         api.initial_controls(mp.solver, np.tile(qp.u_hover, (B, N - 1, 1)))
     else:
-        n = int(what[1:])
-        B = 8192 if n <= 32 else 2048
-        pb = altro.problems.gen_random_linear_batch(B, n=n, m=4, N=50, steps=W + 3 * K, seed=5)
+        import re
+        mm = re.match(r"n(\d+)(?:m(\d+))?", what)
+        n, m = int(mm.group(1)), int(mm.group(2) or 4)
+        B = int(os.environ.get("AB_BATCH", "8192" if n <= 32 else "2048"))
+        pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=50, steps=W + 3 * K, seed=5)
         mp = altro.mpc.BatchMPC(pb)
     mp.initial_solve()
     for i in range(W): mp.step(i)

@@ -30,7 +30,7 @@ for name, a, b, info in funcs:
         if m: labels[m.group(1)] = i
     loops = []
     for i in range(a, b):
-        m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", L[i])
+        m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", L[i])
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             k = sum(1 for x in L[labels[m.group(1)]:i] if isinstr(x))
             if k >= 300: loops.append((labels[m.group(1)], i, m.group(1), k))
