@@ -69,7 +69,10 @@ struct Params {
   double *cost, *cmax, *Jtrace, *ctrace, *atrace;
   long long *n_backward, *n_rollout, *n_trials, *n_solves, *n_iters, *n_ok, *n_gconf, *n_gs;
   double* Qz;           // [B][N][n+m] scratch of the costate sweep: gradient of the AL cost at every knot of plane cur
-  unsigned* bwst;       // [B][136] gain-reuse state between launches: hash per lane [2][64], bw_ok, bw_plain, bw_mu (2 words)
+  unsigned* bwst;       // [B][136] gain-reuse state between launches: word 128 bw_ok, 129 bw_plain, 130-131 bw_mu, 132 the roles of the
+                        // instance's three active-set planes (words 0..127: unused since the hashes went)
+  unsigned char* aset;  // [B][3][N][64] EXACT active sets, one byte per knot and lane (box_code of x_t | box_code of u_t << 2 | row t
+                        // active << 4): the plane of the last backward pass, of the trajectory in plane cur, of the trial in work
   int reuse_ok;         // 0: a setter has changed the model / cost / constraints / options since the last launch
   double* fac;          // [B][N][MC (MC + 1) / 2] (n, m <= 16) L D L' factor of Quu_k of the last backward pass: strictly lower
                         // triangle of L and 1 / D on the diagonal, row-major packed (costate sweep)
@@ -379,9 +382,12 @@ struct Solver {
   double mu, rho, drho;
   int dj_zero, status, iters, iters_outer;
   bool dtiny = false;  // backward(): every feedforward term of the pass is at rounding level, |d_k,a| <= 1e-9 (1 + |u_k,a|)
-  // costate sweep (adjoint_row): per-lane active-set hashes of the last backward pass and of the trajectory whose
-  // plane cur holds; bw_plain: that pass ran without regularisation; qvalid: q_hash describes plane cur
-  unsigned long long bw_hash = 0ull, q_hash = 0ull;  // 64 bits per lane: two independent 32-bit sums (hash_add)
+  // costate sweep (adjoint_row) and gain reuse: the active set of the last backward pass and that of the trajectory plane cur
+  // holds; bw_plain: that pass ran without regularisation; qvalid: plane qp describes plane cur
+  // (rounds 2-3: 32-, then 64-bit hashes per lane.  Round 4: the sets themselves, P.aset -- a byte per knot and lane in HBM, written
+  // next to the trajectory by the rollouts and by the pass while it expands; the three planes of an instance change roles by
+  // index: bwp = the pass's, qp = that of the trajectory in plane cur, ap = the trial's.  Compared byte for byte: sets_differ.)
+  int bwp = 0, qp = 1, ap = 2;
   bool bw_plain = false, qvalid = false;
   bool bw_ok = false;  // Kg and fac hold a backward pass that succeeded (generic class: kept across the solves of a launch)
   double bw_mu = 0.0;  // the penalty it ran at
@@ -436,14 +442,26 @@ struct Solver {
     bool limit;
     bool unchanged;  // closed-loop rollouts: the trial reproduced plane cur bit for bit
     bool tiny;       // closed-loop rollouts: no element moved by more than 1e-7 (1 + |z|)
-    unsigned long long qh;  // row rollouts, closed loop: this lane's active-set hash at the trajectory produced
   };
+
+  __device__ __forceinline__ unsigned char* aset_plane(int pl) const { return P.aset + ((size_t)inst * 3 + (size_t)pl) * (size_t)N * 64; }
+  // the trajectory's active set against the pass's, byte for byte
+  __device__ __forceinline__ bool sets_differ() const {
+    // (any byte anywhere: the planes are read as 16-byte chunks, 1 KB per load instruction of the wave)
+    const uint4 *a = reinterpret_cast<const uint4*>(aset_plane(qp)), *b = reinterpret_cast<const uint4*>(aset_plane(bwp));
+    unsigned diff = 0u;
+    for (int c = T; c < N * 4; c += 64) {
+      const uint4 x = a[c], y = b[c];
+      diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    return wave_any(diff != 0u);
+  }
 
   // ---- the phases as calls (ALTRO_WIDE_SPLIT) or inline ----
   __device__ __forceinline__ PhIn ph_in(double a = 0.0, int i0 = 0) const {
     PhIn in;
     in.cur = cur; in.kref = kref; in.i0 = i0; in.flags = dtiny ? 1 : 0;
-    in.mu = mu; in.rho = rho; in.a = a; in.h = bw_hash;
+    in.mu = mu; in.rho = rho; in.a = a; in.h = (unsigned long long)(bwp | (qp << 2) | (ap << 4));
     return in;
   }
   __device__ __forceinline__ void ph_stamps(const PhOut& o) {
@@ -457,7 +475,7 @@ struct Solver {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
       const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL>(kp, ph_in(alpha));
       RollOut r;
-      r.J = o.a; r.cmax = o.b; r.qh = o.h;
+      r.J = o.a; r.cmax = o.b;
       r.limit = (o.flags & 1) != 0; r.unchanged = (o.flags & 2) != 0; r.tiny = (o.flags & 4) != 0;
       return r;
     } else {
@@ -467,7 +485,7 @@ struct Solver {
   __device__ __forceinline__ bool do_backward(double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
       const PhOut o = wide_phase<MC, SM, PH_BACKWARD>(kp, ph_in());
-      dV1 = o.a; dV2 = o.b; bw_hash = o.h; dtiny = (o.flags & 2) != 0;
+      dV1 = o.a; dV2 = o.b; dtiny = (o.flags & 2) != 0;
       ph_stamps(o);
       return (o.flags & 1) != 0;
     } else {
@@ -955,7 +973,7 @@ struct Solver {
     const double fT = fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
-    unsigned long long qh = 0ull;  // active-set hash of the trajectory produced (costate sweep)
+    unsigned char* const aq = aset_plane(ap) + T;  // active set of the trajectory produced (costate sweep, gain reuse)
     double xb = isx ? x0i[Tn] : 0.0;
     struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
     auto ld = [&](int k) {
@@ -1000,7 +1018,7 @@ struct Solver {
       J += lane_cost_sel(cwx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, bx, viol);
       J += lane_cost_sel(cwu, uv, d.ur, cumax, cumin, d.luh, d.lul, mu, isu, bx, viol);
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
-      qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2), k);
+      aq[(size_t)k * 64] = (unsigned char)(box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2));
       const double xn = dot_lds(grow, 1, zb, 1, nzp, fT);
       wsync();
       xb = isx ? xn : 0.0;
@@ -1011,7 +1029,7 @@ struct Solver {
     wsync();
     J += lane_cost_sel(cwfx, xb, d.xr, cxmax, cxmin, d.lxh, d.lxl, mu, isx, box_at(N - 1), viol);
     lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value));
-    qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & box_at(N - 1)), N - 1);
+    aq[(size_t)(N - 1) * 64] = (unsigned char)box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & box_at(N - 1));
     if (CLOSED) {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
@@ -1023,7 +1041,6 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = CLOSED && !wave_any(chg);
     r.tiny = CLOSED && !wave_any(big);
-    r.qh = qh;
     return r;
   }
 
@@ -1090,7 +1107,7 @@ struct Solver {
     double ab[32];  // row t of [A B]: time-invariant dynamics keep it for the whole rollout, per-knot ones refill it
 #pragma unroll
     for (int c = 0; c < 32; ++c) ab[c] = abrow[c];
-    unsigned long long qh = 0ull;
+    unsigned char* const aq = aset_plane(ap) + t;
     double fT = LTV ? 0.0 : fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
@@ -1235,7 +1252,7 @@ struct Solver {
       if (CLOSED) {  // active-set code of the knot at the trajectory produced (compared with the backward pass's by the costate sweep)
         const unsigned code = box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2) |
                               ((on & act) ? 16u : 0u);
-        qh = hash_add(qh, code, k);
+        aq[(unsigned)k * 64u] = (unsigned char)code;
       }
       double xn = RowDot<16>::run(ab, xb, fT);
       xn = RowDot<16>::run(ab + 16, uv, xn);
@@ -1270,7 +1287,7 @@ struct Solver {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
       const bool bxT = box_at(N - 1);
-      qh = hash_add(qh, box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT) | ((on & act) ? 16u : 0u), N - 1);
+      aq[(unsigned)(N - 1) * 64u] = (unsigned char)(box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT) | ((on & act) ? 16u : 0u));
     }
     block_sync();  // phase end: the trajectory written to global memory is read by other lanes next
     RollOut r;
@@ -1279,7 +1296,6 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = CLOSED && !wave_any(chg);
     r.tiny = CLOSED && !wave_any(big);
-    r.qh = qh;
     return r;
   }
 
@@ -1756,7 +1772,6 @@ struct Solver {
     r.limit = wave_any(lim);
     r.unchanged = !open && !wave_any(chg);
     r.tiny = !open && !wave_any(big);
-    r.qh = 0ull;
     return r;
   }
 
@@ -1784,18 +1799,10 @@ struct Solver {
     }
   }
 
-  // Active-set hash of one lane: a position-weighted sum of the per-knot codes, so that the backward pass (knots in
-  // descending order) and a rollout (ascending) arrive at the same number for the same active set.  Code of lane T at
-  // a knot: bits 0-1 the box sides of x_T that enter the Hessian, bits 2-3 those of u_T, bit 4 generic row T active.
-  // Two independent 32-bit sums packed into 64 bits: the hash of the gains in memory is compared with the active sets
-  // of unrelated later solves, launch after launch (gain reuse), so a collision must be out of reach.
-  static __device__ __forceinline__ unsigned long long hash_add(unsigned long long h, unsigned code, int k) {
-    const unsigned ka = (((unsigned)(2 * k + 1)) * 2654435761u) >> 8;
-    const unsigned kb = (((unsigned)(2 * k + 1)) * 2246822519u) >> 8;
-    const unsigned a = (unsigned)h + __umul24(code, ka);
-    const unsigned b = (unsigned)(h >> 32) + __umul24(code, kb);
-    return ((unsigned long long)b << 32) | (unsigned long long)a;
-  }
+  // Active-set code of lane T at a knot (one byte of P.aset): bits 0-1 the box sides of x_T that enter the Hessian, bits 2-3
+  // those of u_T, bit 4 generic row T active.  The backward pass (knots in descending order) and a rollout (ascending) write
+  // the same byte for the same active set; the set of the gains in memory is compared with the sets of unrelated later
+  // solves, launch after launch (gain reuse): byte for byte, not through a hash.
   static __device__ __forceinline__ unsigned box_code(double z, double zmx, double zmn, double lhi, double llo, bool on) {
     const bool bh = on & (zmx < 1e300), bl = on & (zmn > -1e300);
     const bool ah = ((z - zmx) >= 0.0) | (lhi > 0.0), al = ((zmn - z) >= 0.0) | (llo > 0.0);
@@ -2080,10 +2087,12 @@ struct Solver {
     const int ldg = ly.ldg, lds = ly.lds, ldh = ly.ldh, ldu = ly.ldu;
     for (int e = T; e < np * lds; e += 64) S[e] = 0.0;
     wsync();
-    unsigned long long hash = 0ull;
+    // the active set this pass expands with (a failed pass leaves bw_ok false).  (Addressed from P.aset at every store: a
+    // pointer kept across the knot loop sends hipcc 7.2 into "Illegal instruction detected" in the two-wave instantiations.)
+    const unsigned aoff = (unsigned)(((size_t)inst * 3 + (size_t)bwp) * (size_t)N * 64 + (size_t)T);
     unsigned kcode = 0u;
     expansion(N - 1, true, load_knot(N - 1, true, 2, Xp(cur), Up(cur)), kcode);
-    hash = hash_add(hash, kcode, N - 1);
+    P.aset[aoff + (unsigned)(N - 1) * 64u] = (unsigned char)kcode;
     if (T < n) {
       S[T * lds + T] = hz[T];
       sv[T] = qz[T];
@@ -2108,7 +2117,7 @@ struct Solver {
       if (ahead) dq = dyn_request(k > 0 ? k - 1 : 0);
       else if (P.ltv) load_dyn(k);
       expansion(k, false, kd, kcode);  // ends with a barrier
-      hash = hash_add(hash, kcode, k);
+      P.aset[aoff + (unsigned)k * 64u] = (unsigned char)kcode;
       const double us_k = kd.us;
       kd = kdn;
       WSTAMP(const long long b1 = wstamp(); t_a += b1 - b0;)
@@ -2369,7 +2378,6 @@ struct Solver {
       WSTAMP(t_d += wstamp() - b3;)
     }
     dtiny = !wave_any(dbig);
-    bw_hash = hash;
     return false;
   }
 
@@ -2422,7 +2430,7 @@ struct Solver {
     constexpr bool kReuse = MC > 0 && !SM;
     const bool reuse_class = kReuse && !o.strict && Pn == 0 && !P.ltv;
     if (reuse_class) {
-      q_hash = r0.qh;  // the open-loop rollout's hash of plane cur, with the current duals
+      { const int t_ = qp; qp = ap; ap = t_; }  // the open-loop rollout's set of plane cur, with the current duals
       qvalid = true;
     } else {
       qvalid = false;  // the duals / the penalty may have changed since the hash was taken
@@ -2433,7 +2441,7 @@ struct Solver {
       bool gave_up = false;
       bool swept = false;
       if constexpr (kReuse) {
-        if (reuse_class && bw_ok && bw_plain && qvalid && rho == 0.0 && mu == bw_mu && !wave_any(q_hash != bw_hash)) {
+        if (reuse_class && bw_ok && bw_plain && qvalid && rho == 0.0 && mu == bw_mu && !sets_differ()) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
           dtiny = do_adjoint_lds(true, dV1, dV2);
@@ -2452,7 +2460,7 @@ struct Solver {
       if constexpr (MC > 0) {
         const bool can_sweep = SM ? row_rollouts() : (Pn == 0 && !P.ltv);
         const bool tryg = !swept && !(kReuse && reuse_class) && !o.strict && it >= 1 && bw_plain && qvalid && rho == 0.0 && can_sweep &&
-                          !wave_any(q_hash != bw_hash) && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
+                          !sets_differ() && (grad_tol > 1e-8) && (cost_tol > 1e-10 * (1.0 + fabs(J_prev)));
         if (tryg) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
@@ -2494,7 +2502,6 @@ struct Solver {
       J = __builtin_inf();
       int ls = 0;
       bool accepted = true;
-      unsigned long long qh_acc = 0ull;
       // Default-mode shortcuts, the ones of solve_dpp16.h (altro_opts.strict = 1 takes none of them).  Confirmation
       // iteration: every feedforward term of the backward pass is at rounding level, so the rollout, its line search
       // (20 fruitless halvings whenever the rounding of J falls the wrong way) and the Todorov sweep cannot change
@@ -2524,7 +2531,6 @@ struct Solver {
         const RollOut r = do_rollout(false, alpha);
         WSTAMP(t_ro += wstamp() - ts;)
         if (ls == 0) nro++; else ntr++;
-        qh_acc = r.qh;  // (the last trial run is the accepted one, if any is)
         if (r.limit) { ls++; alpha *= 0.5; continue; }
         J = r.J;
         cm = r.cmax;
@@ -2543,12 +2549,9 @@ struct Solver {
         // step is followed by a confirmation sweep: inside an active set it lands on the minimiser of the quadratic model, a
         // damped one does not, and a sweep that does not confirm costs a quarter of the backward pass it fails to replace
         // (the gain-reuse class sweeps after any accepted step: there the pass always yields the iteration)
-        if (kReuse && reuse_class) {
-          if (accepted) q_hash = qh_acc;
-        } else {
-          qvalid = accepted && alpha == 1.0;
-          q_hash = qh_acc;
-        }
+        // (the last trial run is the accepted one, if any is: its plane becomes the trajectory's)
+        if (accepted) { const int t_ = qp; qp = ap; ap = t_; }
+        if (!(kReuse && reuse_class)) qvalid = accepted && alpha == 1.0;
       }
       if (J > o.max_cost_value) { status = ALTRO_MAXIMUM_COST; break; }
       if (accepted) cur ^= 1;  // copy_trajectories!
@@ -2728,7 +2731,11 @@ struct Solver {
     nbw = nro = ntr = 0;
     {  // the gain-reuse state of the previous launch (one launch of K steps and K launches of one step decide alike)
       const unsigned* st = P.bwst + (size_t)inst * 136;
-      bw_hash = ((unsigned long long)st[64 + T] << 32) | (unsigned long long)st[T];
+      {
+        const unsigned roles = st[132];
+        const int b_ = (int)(roles & 3u), q_ = (int)((roles >> 2) & 3u), a_ = (int)((roles >> 4) & 3u);
+        if (((1 << b_) | (1 << q_) | (1 << a_)) == 7) { bwp = b_; qp = q_; ap = a_; }  // (zeroed state: the default roles)
+      }
       bw_ok = P.reuse_ok != 0 && st[128] != 0u;
       bw_plain = st[129] != 0u;
       bw_mu = __hiloint2double((int)st[131], (int)st[130]);
@@ -2782,9 +2789,8 @@ struct Solver {
     }
     {
       unsigned* st = P.bwst + (size_t)inst * 136;
-      st[T] = (unsigned)bw_hash;
-      st[64 + T] = (unsigned)(bw_hash >> 32);
       if (T == 0) {
+        st[132] = (unsigned)(bwp | (qp << 2) | (ap << 4));
         st[128] = bw_ok ? 1u : 0u;
         st[129] = bw_plain ? 1u : 0u;
         st[130] = (unsigned)__double2loint(bw_mu);
@@ -2812,7 +2818,10 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
   s.kref = __builtin_amdgcn_readfirstlane(in.kref);
   s.mu = uniform_f64(in.mu);
   s.rho = uniform_f64(in.rho);
-  s.bw_hash = in.h;
+  {
+    const int roles = __builtin_amdgcn_readfirstlane((int)in.h);
+    s.bwp = roles & 3; s.qp = (roles >> 2) & 3; s.ap = (roles >> 4) & 3;
+  }
   s.dtiny = (__builtin_amdgcn_readfirstlane(in.flags) & 1) != 0;
   PhOut o;
   o.a = o.b = 0.0;
@@ -2820,12 +2829,12 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
   o.flags = 0;
   if constexpr (OP == PH_ROLL_OPEN || OP == PH_ROLL) {
     const typename Solver<MC, SM>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
-    o.a = r.J; o.b = r.cmax; o.h = r.qh;
+    o.a = r.J; o.b = r.cmax;
     o.flags = (r.limit ? 1 : 0) | (r.unchanged ? 2 : 0) | (r.tiny ? 4 : 0);
   } else if constexpr (OP == PH_BACKWARD) {
     double d1 = 0.0, d2 = 0.0;
     const bool fail = s.backward(d1, d2);
-    o.a = d1; o.b = d2; o.h = s.bw_hash;
+    o.a = d1; o.b = d2;
     o.flags = (fail ? 1 : 0) | (s.dtiny ? 2 : 0);
   } else if constexpr (OP == PH_ADJ_FULL || OP == PH_ADJ_CONF) {
     double d1 = 0.0, d2 = 0.0;

@@ -58,6 +58,7 @@ struct WideBackend {
   double *A = nullptr, *Bm = nullptr, *f = nullptr, *wd = nullptr, *wf = nullptr, *zmin = nullptr, *zmax = nullptr;
   double *x0 = nullptr, *Xref = nullptr, *Uref = nullptr, *X = nullptr, *U = nullptr, *Lb = nullptr, *Lc = nullptr,
          *mu = nullptr, *Kg = nullptr, *dg = nullptr, *trash = nullptr, *AconT = nullptr, *bcon = nullptr, *stage = nullptr, *Qz = nullptr, *fac = nullptr;
+  unsigned char* aset = nullptr;   // [B][3][N][64] exact active sets (solve_wide.h: Params::aset)
   unsigned* bwst = nullptr;   // [B][136] per instance: the state of the gain reuse between launches (solve_wide.h: bw_*)
   int coop_mode = -1, static_mask = 7;  // altro_debug_set "wide_coop", "wide_static_mask" (before create)
   int compact_np_max = 48;  // wide_compact: the LDS carve-up with Qux and K inside W, for padded state dimensions up to this
@@ -133,11 +134,12 @@ struct WideBackend {
     ring.reset();
     bench_ev.reserve(2);
     const size_t B = d.batch, N = d.N, n = d.n, m = d.m, z = n + m;
+    if (B * 3 * N * 64 >= (1ull << 32)) WFAIL(ALTRO_ERR_UNSUPPORTED, "batch x horizon too large for one handle (active-set planes are addressed with 32-bit offsets): split the batch");
     int rc;
 #define DA_(p, c) if ((rc = dalloc(&p, (c)))) return rc
     DA_(wd, z); DA_(wf, n); DA_(zmin, z); DA_(zmax, z);
     DA_(x0, B * n); DA_(X, B * 2 * N * n); DA_(U, B * 2 * (N - 1) * m); DA_(cur, B);
-    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 136);
+    DA_(Lb, B * N * 2 * z); DA_(mu, B); DA_(Kg, B * (N - 1) * n * m); DA_(dg, B * (N - 1) * m); DA_(trash, B * 64); DA_(Qz, B * N * z); DA_(fac, m <= 16 ? B * N * wide_fac_size(m) : 1); DA_(bwst, B * 136); DA_(aset, B * 3 * N * 64);
     DA_(iters, B); DA_(iters_outer, B); DA_(status, B); DA_(cost, B); DA_(cmax, B);
     DA_(Jtrace, B * ALTRO_TRACE_LEN); DA_(ctrace, B * ALTRO_TRACE_LEN); DA_(atrace, B * ALTRO_TRACE_LEN);
     DA_(n_backward, B); DA_(n_rollout, B); DA_(n_trials, B); DA_(n_solves, B); DA_(n_iters, B); DA_(n_ok, B); DA_(n_gconf, B); DA_(n_gs, B);
@@ -160,7 +162,7 @@ struct WideBackend {
     if (stream) hipStreamSynchronize(stream);
     void* ptrs[] = {A, Bm, f, wd, wf, zmin, zmax, x0, Xref, Uref, X, U, Lb, Lc, mu, Kg, dg, trash, AconT, bcon, stage, cur, ctype,
                     rowk0, rowk1, rowc0, rowcp, iters, iters_outer, status, noise_grp, cost, cmax, Jtrace, ctrace, atrace, noise, noise_w,
-                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, n_gs, fac, bwst,
+                    n_backward, n_rollout, n_trials, n_solves, n_iters, n_ok, Xsave, Usave, Qz, n_gconf, n_gs, fac, bwst, aset,
                     pn_ran, pn_failed, pn_dfail, pn_res, pn_dres0, pn_dres, pnE, pndv, pnLd, pnLo, pnvec, pntz, pnblk, pnnb, pnnst, pnrinfo};
     for (void* p : ptrs)
       if (p) hipFree(p);
@@ -436,7 +438,7 @@ struct WideBackend {
     p.x0 = x0; p.Xref = Xref; p.Uref = Uref; p.X = X; p.U = U; p.cur = cur; p.Lb = Lb; p.Lc = Lc; p.mu = mu; p.Kg = Kg; p.dg = dg; p.trash = trash;
     p.iters = iters; p.iters_outer = iters_outer; p.status = status; p.cost = cost; p.cmax = cmax;
     p.Jtrace = Jtrace; p.ctrace = ctrace; p.atrace = atrace;
-    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.n_gs = n_gs; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.reuse_ok = (gains_valid || debug_keep_gains) ? 1 : 0;
+    p.n_backward = n_backward; p.n_rollout = n_rollout; p.n_trials = n_trials; p.n_solves = n_solves; p.n_iters = n_iters; p.n_ok = n_ok; p.n_gconf = n_gconf; p.n_gs = n_gs; p.Qz = Qz; p.fac = fac; p.bwst = bwst; p.aset = aset; p.reuse_ok = (gains_valid || debug_keep_gains) ? 1 : 0;
     p.noise = noise; p.noise_w = noise_w; p.noise_grp = noise_grp; p.noise_mode = noise_mode; p.mpc_shift = mpc_shift;
     p.kref = kref;
     p.dyn_blocks = dyn_blocks; p.dyn_step_stride = dyn_step_stride;
