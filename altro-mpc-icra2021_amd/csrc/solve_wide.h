@@ -318,7 +318,7 @@ __device__ __forceinline__ long long wstamp() {
 #ifndef ALTRO_WIDE_SPLIT
 #define ALTRO_WIDE_SPLIT 1
 #endif
-enum { PH_ROLL_OPEN = 0, PH_ROLL, PH_BACKWARD, PH_ADJ_FULL, PH_ADJ_CONF, PH_GRAD_ADJ_ROW, PH_DUAL, PH_SHIFT, PH_PLANT };
+enum { PH_ROLL_OPEN = 0, PH_ROLL, PH_BACKWARD, PH_ADJ_FULL, PH_ADJ_CONF, PH_GRAD_ADJ_ROW, PH_DUAL, PH_SHIFT, PH_PLANT, PH_GRAD_ADJ_ROW_FULL };
 struct PhIn {
   int cur, kref, i0, flags;
   double mu, rho, a;
@@ -507,6 +507,28 @@ struct Solver {
       return P.ltv ? adjoint_row<true>() : adjoint_row<false>();
     } else {
       return false;
+    }
+  }
+  // gain reuse in the n, m <= 16 instantiation with m <= 4: box constraints only, time-invariant dynamics, row rollouts.
+  // Measured over 30 fused steps at batch 8192 (tools/debug/gpu_wide_ab.py): n = 16, m = 4: 81.4 -> 75.8 ms; with m <= 8 as
+  // well, (12, 6): 121 -> 128 ms -- the pass of these sizes is a chain of register-resident tiles, and the sweep with six
+  // columns of K per lane costs more than the share of passes it replaces.
+  static constexpr bool kReuseRow = SM && MC == 4;
+  __device__ __forceinline__ bool grad_adjoint_row_full(double& dV1, double& dV2) {
+    if constexpr (kReuseRow) {
+      grad_pass<false>();
+      return adjoint_row<false, true>(&dV1, &dV2);
+    } else {
+      return false;
+    }
+  }
+  __device__ __forceinline__ bool do_grad_adjoint_row_full(double& dV1, double& dV2) {
+    if constexpr (ALTRO_WIDE_SPLIT != 0) {
+      const PhOut o = wide_phase<MC, SM, PH_GRAD_ADJ_ROW_FULL>(kp, ph_in());
+      dV1 = o.a; dV2 = o.b;
+      return (o.flags & 1) != 0;
+    } else {
+      return grad_adjoint_row_full(dV1, dV2);
     }
   }
   __device__ __forceinline__ bool do_grad_adjoint_row() {
@@ -1108,6 +1130,9 @@ struct Solver {
 #pragma unroll
     for (int c = 0; c < 32; ++c) ab[c] = abrow[c];
     unsigned char* const aq = aset_plane(ap) + t;
+    // closed-loop rollouts record the active set of the trajectory they produce; in the gain-reuse class the open-loop one
+    // does too (the set of plane cur under the current duals, compared with the stored pass's at the start of a solve)
+    constexpr bool CODES = CLOSED || (kReuseRow && !ROWS && !LTV);
     double fT = LTV ? 0.0 : fk(0)[Tn];
     double J = 0.0, viol = 0.0;
     bool lim = false, chg = false, big = false;
@@ -1249,7 +1274,7 @@ struct Solver {
         viol = fmax(viol, on ? (eq ? fabs(v) : v) : 0.0);
       }
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
-      if (CLOSED) {  // active-set code of the knot at the trajectory produced (compared with the backward pass's by the costate sweep)
+      if (CODES) {  // active-set code of the knot at the trajectory produced (compared with the backward pass's by the costate sweep)
         const unsigned code = box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2) |
                               ((on & act) ? 16u : 0u);
         aq[(unsigned)k * 64u] = (unsigned char)code;
@@ -1286,6 +1311,8 @@ struct Solver {
     if (CLOSED) {
       chg = chg | (isx & (xb != d.xs));
       big = big | (isx & !(fabs(xb - d.xs) <= 1e-7 * (1.0 + fabs(d.xs))));
+    }
+    if (CODES) {
       const bool bxT = box_at(N - 1);
       aq[(unsigned)(N - 1) * 64u] = (unsigned char)(box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bxT) | ((on & act) ? 16u : 0u));
     }
@@ -1394,8 +1421,13 @@ struct Solver {
   // Lane T holds lambda_T, g_T; column T of A_k and of B_k in registers (time-invariant: loaded once; per-knot
   // dynamics: from the blocks parked in LDS, requested two knots ahead as in the rollouts); the factor of knot k is
   // parked in LDS a knot ahead and every lane solves for the whole d_k.
-  template <bool LTV>
-  __device__ __forceinline__ bool adjoint_row() {
+  // FULL (time-invariant dynamics, box constraints only, MC = 4): the first-order half of a whole iteration, as
+  // adjoint_lds(full) for the larger sizes -- the gains K_k in memory stay (the caller has established that a backward pass
+  // here would reproduce them), the costate runs s_k = Qx + K_k' Qu, the feedforward terms d_k = -Quu_k^-1 Qu are written
+  // out and the expected decrease (dV1, dV2) is returned.
+  template <bool LTV, bool FULL = false>
+  __device__ __forceinline__ bool adjoint_row(double* dV1 = nullptr, double* dV2 = nullptr) {
+    static_assert(!(LTV && FULL), "gain reuse: time-invariant dynamics only");
     constexpr int MP = MC > 0 ? MC : 4, FS = MP * (MP + 1) / 2;
     int t = T;
     asm volatile("" : "+v"(t));
@@ -1456,6 +1488,7 @@ struct Solver {
     };
     struct Qk {
       double qx, qu, us;
+      double kc[FULL ? MP : 1];  // FULL: column t of K_k
     };
     auto ldq = [&](int kk) __attribute__((always_inline)) {
       const unsigned k = kk > 0 ? kk : 0;
@@ -1463,8 +1496,16 @@ struct Solver {
       q.qx = ldg(Qzi, k * nz + Tn);
       q.qu = ldg(Qzi, k * nz + n + Tm);
       q.us = ldg(Us, k * m + Tm);
+      if constexpr (FULL) {
+#pragma unroll
+        for (int a_ = 0; a_ < MP; ++a_) q.kc[a_] = ldg(Kgi, k * (unsigned)(n * m) + Tn * m + (a_ < m ? a_ : m - 1));
+      } else {
+        q.kc[0] = 0.0;
+      }
       return q;
     };
+    double dv1 = 0.0;
+    double* gtr = P.trash + (size_t)inst * 64 + t;
     lds_d* const park[2] = {(lds_d*)W, (lds_d*)Hux};
     lds_d* const fpark[2] = {(lds_d*)S, (lds_d*)S + 136};
     DynRegs dq[2] = {};
@@ -1505,6 +1546,11 @@ struct Solver {
       // d_k = Quu_k^-1 g_k (the sign does not matter here), every lane for the whole vector
       double y[MP];
       gather_row<MP>(y, gu);
+      double sx = gx;
+      if constexpr (FULL) {  // s_k = Qx + K_k' Qu (gu is zero beyond m)
+#pragma unroll
+        for (int a_ = 0; a_ < MP; ++a_) sx += qs[U].kc[a_] * y[a_];
+      }
       const lds_d* fk = fpark[k & 1];
 #pragma unroll
       for (int j = 0; j < MP; ++j)          // forward: L y = g
@@ -1520,7 +1566,11 @@ struct Solver {
 #pragma unroll
       for (int r = 0; r < MP; ++r) dsel = (t == r) ? y[r] : dsel;
       dbig = dbig | (live & isu & !(fabs(dsel) <= 1e-9 * (1.0 + fabs(qs[U].us))));
-      lam = (live & isx) ? gx : lam;
+      if constexpr (FULL) {
+        *((live & isu) ? dgi + (unsigned)(k > 0 ? k : 0) * m + t : gtr) = 0.0 - dsel;
+        dv1 -= (live & isu) ? dsel * gu : 0.0;
+      }
+      lam = (live & isx) ? sx : lam;
       fac_park(fq[(U + 1) & 1], fpark[(k - 1) & 1]);
       if constexpr (LTV) dyn_park(dq[(U + 1) & 1], park[(k - 1) & 1]);
       wsync();
@@ -1530,6 +1580,11 @@ struct Solver {
       knot(std::integral_constant<int, 1>{}, k - 1);
       knot(std::integral_constant<int, 2>{}, k - 2);
       knot(std::integral_constant<int, 3>{}, k - 3);
+    }
+    if constexpr (FULL) {
+      block_sync();  // the feedforward terms are read by the rollout
+      *dV1 = wave_sum(dv1);
+      *dV2 = -0.5 * *dV1;
     }
     return !wave_any(dbig);
   }
@@ -2427,8 +2482,8 @@ struct Solver {
     // trajectory in plane cur has (hashes), a new pass would return the same K -- also across the MPC solves of a
     // launch (60-67 % of the headline-type solves end with the active set they started with).  Such an iteration
     // takes K from memory and its feedforward terms and expected decrease from adjoint_lds(full).
-    constexpr bool kReuse = MC > 0 && !SM;
-    const bool reuse_class = kReuse && !o.strict && Pn == 0 && !P.ltv;
+    constexpr bool kReuse = (MC > 0 && !SM) || kReuseRow;
+    const bool reuse_class = kReuse && !o.strict && Pn == 0 && !P.ltv && (!SM || row_rollouts());
     if (reuse_class) {
       { const int t_ = qp; qp = ap; ap = t_; }  // the open-loop rollout's set of plane cur, with the current duals
       qvalid = true;
@@ -2444,7 +2499,8 @@ struct Solver {
         if (reuse_class && bw_ok && bw_plain && qvalid && rho == 0.0 && mu == bw_mu && !sets_differ()) {
           phase_begin();
           WSTAMP(const long long ts = wstamp();)
-          dtiny = do_adjoint_lds(true, dV1, dV2);
+          if constexpr (SM) dtiny = do_grad_adjoint_row_full(dV1, dV2);
+          else dtiny = do_adjoint_lds(true, dV1, dV2);
           WSTAMP(t_td += wstamp() - ts;)
           swept = true;
           ngs++;
@@ -2843,6 +2899,10 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
     o.flags = ok ? 1 : 0;
   } else if constexpr (OP == PH_GRAD_ADJ_ROW) {
     o.flags = s.grad_adjoint_row() ? 1 : 0;
+  } else if constexpr (OP == PH_GRAD_ADJ_ROW_FULL) {
+    double d1 = 0.0, d2 = 0.0;
+    o.flags = s.grad_adjoint_row_full(d1, d2) ? 1 : 0;
+    o.a = d1; o.b = d2;
   } else if constexpr (OP == PH_DUAL) {
     s.dual_update();
   } else if constexpr (OP == PH_SHIFT) {

@@ -1319,9 +1319,9 @@ def test_per_knot_dynamics_on_a_16_lane_size_move_to_the_wide_kernel(oracle):
         check_against_oracle(st, X, U, b, o, o.solve())
 
 
-@pytest.mark.parametrize("n,m,N", [(24, 4, 30), (12, 4, 30), (8, 4, 21)])
+@pytest.mark.parametrize("n,m,N", [(24, 4, 30), (16, 4, 30), (12, 4, 30), (8, 4, 21)])
 def test_gain_reuse_is_dropped_by_every_setter_the_gains_depend_on(oracle, n, m, N):
-    """Box-only, time-invariant problems (the wide kernel for n > 16, the 16-lane kernels otherwise): in the default mode
+    """Box-only, time-invariant problems (the wide kernel's generic instantiation for n > 16, its single-tile one at (16, 4), the 16-lane kernels otherwise): in the default mode
     iterations whose active set and penalty match the stored backward pass take their gains from memory, also across
     solves and launches.  Everything the gains depend on must drop them -- a new model (set_dynamics), new options
     (another penalty), new cost weights -- and everything the ACTIVE SET depends on must be seen by the hash that guards
