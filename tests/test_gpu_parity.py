@@ -705,10 +705,13 @@ def test_instance_results_do_not_depend_on_batch(oracle):
     assert np.array_equal(altro.states(mp1.solver)[0], Xall[5])
 
 
-def test_fused_multi_step_launch_is_bit_identical_to_single_steps():
-    """altro_mpc_run_async(first, n) == n calls of altro_mpc_step_async, bit for bit."""
+@pytest.mark.parametrize("n,m,N", [(12, 4, 50), (16, 4, 50), (24, 4, 30)])
+def test_fused_multi_step_launch_is_bit_identical_to_single_steps(n, m, N):
+    """altro_mpc_run_async(first, n) == n calls of altro_mpc_step_async, bit for bit -- on the 16-lane kernel and on both
+    gain-reuse classes of the one-wave-per-instance kernel ((16, 4): single tile, (24, 4): generic), whose stored gains, exact
+    active sets and the roles of their planes have to survive the end of a launch exactly as they stood."""
     B, S = 37, 9
-    pb = altro.problems.gen_random_linear_batch(B, steps=S, seed=13)
+    pb = altro.problems.gen_random_linear_batch(B, n=n, m=m, N=N, steps=S, seed=13)
     a = altro.mpc.BatchMPC(pb)
     b = altro.mpc.BatchMPC(pb)
     a.initial_solve()
