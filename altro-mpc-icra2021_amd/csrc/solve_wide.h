@@ -997,7 +997,35 @@ struct Solver {
     bool lim = false, chg = false, big = false;
     unsigned char* const aq = aset_plane(ap) + T;  // active set of the trajectory produced (costate sweep, gain reuse)
     double xb = isx ? x0i[Tn] : 0.0;
-    struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[16]; };
+    // K_k (m x n) travels as a whole block: requested a knot ahead with coalesced loads (n m / 64 per lane), parked in LDS
+    // (the two halves of S, scratch outside the backward pass) at the end of the knot before, read from there by the m lanes
+    // that form u_k.  Until round 4 the first sixteen columns came through registers and the rest was read from global memory
+    // INSIDE the knot's chain -- (n - 16) / 8 exposed round trips per knot, half of a rollout knot at n = 32.  Same terms in the
+    // same order.  (m > 16: the old path.)
+    constexpr bool KLDS = MC > 0;
+    constexpr int KR = MC > 0 ? MC : 1;
+    const unsigned nm_ = (unsigned)(n * m);
+    lds_d* const kbuf[2] = {(lds_d*)S, (lds_d*)S + nm_};
+    lds_d* const ktrash = (lds_d*)zb + nzp;
+    struct KB { double v[KR]; };
+    auto k_req = [&](int kk) __attribute__((always_inline)) {
+      const unsigned ku = kk < N - 1 ? kk : N - 2;
+      KB r;
+#pragma unroll
+      for (int u = 0; u < KR; ++u) {
+        const unsigned e = T + 64 * u;
+        r.v[u] = (CLOSED && KLDS) ? ldg(Kgi, ku * nm_ + (e < nm_ ? e : nm_ - 1)) : 0.0;
+      }
+      return r;
+    };
+    auto k_put = [&](const KB& r, lds_d* st) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < KR; ++u) {
+        const unsigned e = T + 64 * u;
+        *(e < nm_ ? st + e : ktrash) = r.v[u];
+      }
+    };
+    struct Ld { double xs, us, dgv, xr, ur, lxh, lxl, luh, lul, kp[KLDS ? 1 : 16]; };
     auto ld = [&](int k) {
       Ld d;
       const int ku = k < N - 1 ? k : N - 2;     // the terminal knot has no control: clamp, its control terms are switched off
@@ -1010,13 +1038,23 @@ struct Solver {
       d.luh = Lbi[((size_t)ku * 2 + 0) * nz + n + Tm];
       d.lul = Lbi[((size_t)ku * 2 + 1) * nz + n + Tm];
       d.dgv = CLOSED ? dgi[(size_t)ku * m + Tm] : 0.0;
+      if constexpr (KLDS) {
+        d.kp[0] = 0.0;
+      } else {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) d.kp[u] = CLOSED ? Kgi[(size_t)ku * n * m + (size_t)(u < n ? u : n - 1) * m + Tm] : 0.0;
+        for (int u = 0; u < 16; ++u) d.kp[u] = CLOSED ? Kgi[(size_t)ku * n * m + (size_t)(u < n ? u : n - 1) * m + Tm] : 0.0;
+      }
       return d;
     };
     Ld d = ld(0);
+    if constexpr (CLOSED && KLDS) {
+      const KB k0 = k_req(0);
+      k_put(k0, kbuf[0]);
+    }
     for (int k = 0; k < N - 1; ++k) {
       const Ld dn = ld(k + 1);
+      KB kn;
+      if constexpr (CLOSED && KLDS) kn = k_req(k + 1);
       const bool bx = box_at(k);
       *zslot = xb;
       if (CLOSED) *dslot = xb - d.xs;
@@ -1025,9 +1063,24 @@ struct Solver {
       double acc = d.us;
       if (CLOSED) {
         acc += alpha * d.dgv;
+        if constexpr (KLDS) {
+          const lds_d* st = kbuf[k & 1];
+          const lds_d* dv = (const lds_d*)dxv;
+          for (int j0 = 0; j0 < np; j0 += 8) {
+            double x[8], y[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += d.kp[u] * dxv[u];
-        if (n > 16) acc = dot_strided(Kgi + (size_t)k * n * m + (size_t)16 * m + Tm, m, dxv + 16, n - 16, acc);
+            for (int u = 0; u < 8; ++u) {
+              x[u] = st[(unsigned)(j0 + u < n ? j0 + u : n - 1) * (unsigned)m + (unsigned)Tm];
+              y[u] = dv[j0 + u];  // zero beyond n
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += x[u] * y[u];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += d.kp[u] * dxv[u];
+          if (n > 16) acc = dot_strided(Kgi + (size_t)k * n * m + (size_t)16 * m + Tm, m, dxv + 16, n - 16, acc);
+        }
         *(isu ? Ud + (size_t)k * m + T : gtrash) = acc;
       }
       const double uv = acc;
@@ -1042,6 +1095,7 @@ struct Solver {
       lim = lim | (isx & !(fabs(xb) <= P.o.max_state_value)) | (isu & !(fabs(uv) <= P.o.max_control_value));
       aq[(size_t)k * 64] = (unsigned char)(box_code(xb, cxmax, cxmin, d.lxh, d.lxl, isx & bx) | (box_code(uv, cumax, cumin, d.luh, d.lul, isu & bx) << 2));
       const double xn = dot_lds(grow, 1, zb, 1, nzp, fT);
+      if constexpr (CLOSED && KLDS) k_put(kn, kbuf[(k + 1) & 1]);  // block k + 1 (its loads had the knot to arrive)
       wsync();
       xb = isx ? xn : 0.0;
       d = dn;
@@ -1610,10 +1664,13 @@ struct Solver {
     lds_d* const gvec = (lds_d*)qv;                         // g_k, zero beyond m
     struct Qk {
       double xs, us, xr, ur, lxh, lxl, luh, lul, f[3];
+      double kc[MP];  // full: column Tn of K_k, requested with the knot's other operands (round 4: it was read inside the knot)
     };
     auto ldq = [&](int kk) __attribute__((always_inline)) {
       const unsigned k = kk > 0 ? kk : 0;
       Qk q;
+#pragma unroll
+      for (int a_ = 0; a_ < MP; ++a_) q.kc[a_] = full ? ldg(Kgi, k * (unsigned)(n * m) + Tn * m + (a_ < m ? a_ : m - 1)) : 0.0;
       q.xs = ldg(Xs, k * n + Tn);
       q.xr = ldg(Xri, (kref + k) * n + Tn);
       q.lxh = ldg(Lbi, (k * 2 + 0) * nz + Tn);
@@ -1670,15 +1727,11 @@ struct Solver {
       {  // s_k = Qx + K_k' Qu (with d = 0, the confirmation test, the second term is at rounding level: it is left out)
         double sx = gx;
         if (full) {
-          const unsigned kk = k > 0 ? k : 0;
-          double kc[16], gq[16];
+          double gq[MP];
 #pragma unroll
-          for (int a_ = 0; a_ < 16; ++a_) {
-            kc[a_] = ldg(Kgi, kk * (unsigned)(n * m) + Tn * m + (a_ < m ? a_ : m - 1));
-            gq[a_] = gvec[a_];  // zero beyond m
-          }
+          for (int a_ = 0; a_ < MP; ++a_) gq[a_] = gvec[a_];  // zero beyond m
 #pragma unroll
-          for (int a_ = 0; a_ < 16; ++a_) sx += kc[a_] * gq[a_];
+          for (int a_ = 0; a_ < MP; ++a_) sx += q.kc[a_] * gq[a_];
         }
         for (int c = T; c < np; c += 64) lamb[U ^ 1][c] = (c < n) ? sx : 0.0;
       }
