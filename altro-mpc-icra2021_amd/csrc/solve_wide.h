@@ -318,6 +318,7 @@ __device__ __forceinline__ long long wstamp() {
 #ifndef ALTRO_WIDE_SPLIT
 #define ALTRO_WIDE_SPLIT 1
 #endif
+
 enum { PH_ROLL_OPEN = 0, PH_ROLL, PH_BACKWARD, PH_ADJ_FULL, PH_ADJ_CONF, PH_GRAD_ADJ_ROW, PH_DUAL, PH_SHIFT, PH_PLANT, PH_GRAD_ADJ_ROW_FULL };
 struct PhIn {
   int cur, kref, i0, flags;
@@ -332,12 +333,16 @@ struct PhOut {
   long long t[5];
 #endif
 };
-template <int MC, bool SM, int OP>
+template <int MC, bool SM, int OP, int NPC>
 __device__ PhOut wide_phase(unsigned long long kp, PhIn in);
 struct Resume {};
 
-template <int MC, bool SM>
+// NPC: the padded state dimension as a compile-time constant (32, 48, 64; 0 = read from Params).  What SM does for n <= 16 --
+// leading dimensions, tile counts and trip counts of the product loops known to the compiler -- for the sizes of BASELINE
+// configs[3]: measured at n = 32, m = 4, batch 8192, 30 fused steps: 207 -> 158 ms, bit-identical (round 4).
+template <int MC, bool SM, int NPC = 0>
 struct Solver {
+  static_assert(!(SM && NPC != 0), "SM fixes the padded size at 16");
   const Params& P;
   unsigned long long kp = 0ull;  // the kernel's argument segment (what a phase function rebuilds P from)
   int T;  // lane index; made opaque again at the start of every phase (phase_begin)
@@ -399,14 +404,14 @@ struct Solver {
   double cwx = 0.0, cwfx = 0.0, cxmax = __builtin_inf(), cxmin = -__builtin_inf(), cwu = 0.0, cumax = __builtin_inf(), cumin = -__builtin_inf();
 
   __device__ __forceinline__ Solver(const Params& p, double* lds)
-      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
-        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
+      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : NPC ? NPC : p.np), mp(SM ? 16 : NPC ? 16 : p.mp), nz(p.n + p.m),
+        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
     init(lds, true);
   }
   // a phase function's view of the same instance: same pointers, LDS as the kernel left it
   __device__ __forceinline__ Solver(const Params& p, double* lds, Resume)
-      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : p.np), mp(SM ? 16 : p.mp), nz(p.n + p.m),
-        nzp(SM ? 32 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : p.n, SM ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
+      : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : NPC ? NPC : p.np), mp(SM ? 16 : NPC ? 16 : p.mp), nz(p.n + p.m),
+        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(p.Pn), Pp(p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, p.Pn, SM ? 0 : p.compact)) {
     init(lds, false);
   }
   __device__ __forceinline__ void init(double* lds, bool fresh) {
@@ -473,7 +478,7 @@ struct Solver {
   }
   __device__ __forceinline__ RollOut do_rollout(bool open, double alpha) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL>(kp, ph_in(alpha));
+      const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN, NPC>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL, NPC>(kp, ph_in(alpha));
       RollOut r;
       r.J = o.a; r.cmax = o.b;
       r.limit = (o.flags & 1) != 0; r.unchanged = (o.flags & 2) != 0; r.tiny = (o.flags & 4) != 0;
@@ -484,7 +489,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_backward(double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = wide_phase<MC, SM, PH_BACKWARD>(kp, ph_in());
+      const PhOut o = wide_phase<MC, SM, PH_BACKWARD, NPC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b; dtiny = (o.flags & 2) != 0;
       ph_stamps(o);
       return (o.flags & 1) != 0;
@@ -494,7 +499,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_adjoint_lds(bool full, double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = full ? wide_phase<MC, SM, PH_ADJ_FULL>(kp, ph_in()) : wide_phase<MC, SM, PH_ADJ_CONF>(kp, ph_in());
+      const PhOut o = full ? wide_phase<MC, SM, PH_ADJ_FULL, NPC>(kp, ph_in()) : wide_phase<MC, SM, PH_ADJ_CONF, NPC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b;
       return (o.flags & 1) != 0;
     } else {
@@ -524,7 +529,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_grad_adjoint_row_full(double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = wide_phase<MC, SM, PH_GRAD_ADJ_ROW_FULL>(kp, ph_in());
+      const PhOut o = wide_phase<MC, SM, PH_GRAD_ADJ_ROW_FULL, NPC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b;
       return (o.flags & 1) != 0;
     } else {
@@ -532,19 +537,19 @@ struct Solver {
     }
   }
   __device__ __forceinline__ bool do_grad_adjoint_row() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) return (wide_phase<MC, SM, PH_GRAD_ADJ_ROW>(kp, ph_in()).flags & 1) != 0;
+    if constexpr (ALTRO_WIDE_SPLIT != 0) return (wide_phase<MC, SM, PH_GRAD_ADJ_ROW, NPC>(kp, ph_in()).flags & 1) != 0;
     else return grad_adjoint_row();
   }
   __device__ __forceinline__ void do_dual_update() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_DUAL>(kp, ph_in());
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_DUAL, NPC>(kp, ph_in());
     else dual_update();
   }
   __device__ __forceinline__ void do_shift() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_SHIFT>(kp, ph_in());
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_SHIFT, NPC>(kp, ph_in());
     else shift(true, true);
   }
   __device__ __forceinline__ void do_plant_step(int step) {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_PLANT>(kp, ph_in(0.0, step));
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_PLANT, NPC>(kp, ph_in(0.0, step));
     else plant_step(step);
   }
 
@@ -2916,13 +2921,13 @@ __device__ __forceinline__ double uniform_f64(double v) {
 
 // One phase of the solver as a function of its own (see PhIn above).  The arguments arrive in VGPRs: what is wave-uniform is
 // made scalar again first thing, so that addresses and loop bounds derived from it stay in the scalar unit.
-template <int MC, bool SM, int OP>
+template <int MC, bool SM, int OP, int NPC>
 __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhIn in) {
   extern __shared__ double lds[];
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kp), hi = __builtin_amdgcn_readfirstlane((unsigned)(kp >> 32));
   typedef const __attribute__((address_space(4))) Params* KP;   // the kernel-argument segment: constant memory, scalar loads
   const Params& P = *(const Params*)(KP)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-  Solver<MC, SM> s(P, lds, Resume{});
+  Solver<MC, SM, NPC> s(P, lds, Resume{});
   s.cur = __builtin_amdgcn_readfirstlane(in.cur);
   s.kref = __builtin_amdgcn_readfirstlane(in.kref);
   s.mu = uniform_f64(in.mu);
@@ -2937,7 +2942,7 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
   o.h = 0ull;
   o.flags = 0;
   if constexpr (OP == PH_ROLL_OPEN || OP == PH_ROLL) {
-    const typename Solver<MC, SM>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
+    const typename Solver<MC, SM, NPC>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
     o.a = r.J; o.b = r.cmax;
     o.flags = (r.limit ? 1 : 0) | (r.unchanged ? 2 : 0) | (r.tiny ? 4 : 0);
   } else if constexpr (OP == PH_BACKWARD) {
@@ -2981,14 +2986,14 @@ constexpr int wide_waves(int MC, bool SM) { return SM ? (MC <= 8 ? ALTRO_WIDE_WA
 
 // threads per block: the n, m <= 16 instantiations are always one wave; the others may be launched as a cooperative
 // block of four (wide_block_threads)
-template <int MC, bool SM>
+template <int MC, bool SM, int NPC = 0>
 __global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
   if (!SM && threadIdx.x >= 64) {  // helper waves: no solver state, only products on command
     coop_helper(lds, lds_layout(P.n, P.m, P.Pn, P.compact).cmd);
     return;
   }
-  Solver<MC, SM> s(P, lds);
+  Solver<MC, SM, NPC> s(P, lds);
   s.kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();   // P is the first argument: offset 0
   s.run(mpc, first_step, nsteps);
 }
@@ -3021,7 +3026,11 @@ inline wide_kernel_t wide_kernel_for(int n, int m) {
 #else
   const bool sm = n <= 16 && m <= 16;
   switch (wide_class(m)) {
-    case 4: return sm ? wide_kernel<4, true> : wide_kernel<4, false>;
+    case 4: {   // the m <= 4 sweeps of the reference (state dimension 2 .. 64): padded n compile-time
+      if (sm) return wide_kernel<4, true>;
+      const int np = (n + 15) & ~15;
+      return np == 32 ? wide_kernel<4, false, 32> : np == 48 ? wide_kernel<4, false, 48> : np == 64 ? wide_kernel<4, false, 64> : wide_kernel<4, false>;
+    }
     case 8: return sm ? wide_kernel<8, true> : wide_kernel<8, false>;
     case 12: return sm ? wide_kernel<12, true> : wide_kernel<12, false>;
     case 16: return sm ? wide_kernel<16, true> : wide_kernel<16, false>;
