@@ -3031,9 +3031,10 @@ inline wide_kernel_t wide_kernel_for(int n, int m) {
       const int np = (n + 15) & ~15;
       return np == 32 ? wide_kernel<4, false, 32> : np == 48 ? wide_kernel<4, false, 48> : np == 64 ? wide_kernel<4, false, 64> : wide_kernel<4, false>;
     }
-    case 8: return sm ? wide_kernel<8, true> : wide_kernel<8, false>;
-    case 12: return sm ? wide_kernel<12, true> : wide_kernel<12, false>;
-    case 16: return sm ? wide_kernel<16, true> : wide_kernel<16, false>;
+    // (m = 5 .. 16: the reference's control-dimension sweep runs at n = 30 -- padded 32)
+    case 8: return sm ? wide_kernel<8, true> : ((n + 15) & ~15) == 32 ? wide_kernel<8, false, 32> : wide_kernel<8, false>;
+    case 12: return sm ? wide_kernel<12, true> : ((n + 15) & ~15) == 32 ? wide_kernel<12, false, 32> : wide_kernel<12, false>;
+    case 16: return sm ? wide_kernel<16, true> : ((n + 15) & ~15) == 32 ? wide_kernel<16, false, 32> : wide_kernel<16, false>;
     default: return wide_kernel<0, false>;
   }
 #endif

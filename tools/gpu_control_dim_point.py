@@ -23,4 +23,4 @@ for w in range(2):
     ns, ni, nok = altro.solve_counters(mp.solver)
     out.append({"window": w, "solves_per_s": B * K / dt, "kernel_ms": float(altro.timing_get(mp.solver).sum()), "iterations_mean": float(ni.sum() / ns.sum()),
                 "solve_succeeded_frac": float(nok.sum() / ns.sum())})
-print(json.dumps({"point": "random_linear_mpc n=30 m=%d N=21" % m, "batch": B, "steps": K, "kernel": "altro_wide::wide_kernel<%d, false>" % (0 if m > 16 else 16 if m > 12 else 12 if m > 8 else 8 if m > 4 else 4), "windows": out}))
+print(json.dumps({"point": "random_linear_mpc n=30 m=%d N=21" % m, "batch": B, "steps": K, "kernel": ("altro_wide::wide_kernel<0, false>" if m > 16 else "altro_wide::wide_kernel<%d, false, 32>" % (16 if m > 12 else 12 if m > 8 else 8 if m > 4 else 4)), "windows": out}))
