@@ -5,6 +5,7 @@ calls raise.  Nothing in this package computes a solve on the CPU.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,17 +66,34 @@ class AltroError(RuntimeError):
 
 
 def build(force=False, verbose=False):
-    """Generate the DPP block include and compile the HIP library for gfx950, in tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "pn_polish.h", "pn_wide.h", "gen_dpp_blocks.py")]
+    """Generate the DPP block include and compile the HIP library for gfx950, in tree.  The library is several translation
+    units (altro_batch.hip: the C-ABI, the 16-lane kernels, the polish; wide_inst.hip once per group of one-wave-per-instance
+    kernels, solve_wide.h ALTRO_WIDE_KERNELS) compiled side by side -- one after the other they take ~6 minutes."""
+    srcs = [os.path.join(CSRC, f) for f in ("altro_batch.hip", "wide_inst.hip", "solve_dpp16.h", "solve_wide.h", "wide_backend.h", "launch_ring.h", "pn_polish.h", "pn_wide.h", "gen_dpp_blocks.py")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "altro_batch.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     subprocess.check_call(["python3", os.path.join(CSRC, "gen_dpp_blocks.py"), os.path.join(CSRC, "dpp_blocks.inc")])
     # -amdgpu-mfma-vgpr-form: keep the FP64 MFMA accumulators of solve_wide.h in VGPRs; without it hipcc
     # (ROCm 7.2) shuttles them through AGPRs around every MFMA of the k loop (64 v_accvgpr moves per step)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-           "-o", LIB_PATH, os.path.join(CSRC, "altro_batch.hip")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(CSRC, "solve_wide.h")) as f:
+        ntu = int(re.search(r"constexpr int kWideTUs = (\d+);", f.read()).group(1))
+    jobs = [(os.path.join(objdir, "altro_batch.o"), ["hipcc"] + flags + ["-c", "-o", os.path.join(objdir, "altro_batch.o"), os.path.join(CSRC, "altro_batch.hip")])]
+    for k in range(ntu):
+        o = os.path.join(objdir, "wide_inst_%d.o" % k)
+        jobs.append((o, ["hipcc"] + flags + ["-DALTRO_WIDE_TU=%d" % k, "-c", "-o", o, os.path.join(CSRC, "wide_inst.hip")]))
+    procs = []
+    for o, cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [o for o, _ in jobs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -17,6 +17,11 @@
 #include "launch_ring.h"
 #include "pn_polish.h"
 #include "solve_dpp16.h"
+// The one-wave-per-instance kernels are compiled in translation units of their own (wide_inst.hip, _lib.build) and only
+// declared here; -DALTRO_WIDE_SINGLE_TU (and the development builds) instantiate them in this unit as before.
+#if !defined(ALTRO_WIDE_SINGLE_TU) && !defined(ALTRO_DEV_HEADLINE_ONLY)
+#define ALTRO_WIDE_EXTERN
+#endif
 #include "wide_backend.h"
 
 using altro::IPW;
