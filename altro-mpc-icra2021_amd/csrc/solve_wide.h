@@ -261,6 +261,25 @@ __device__ __forceinline__ void coop_exec(double* lds, const CoopCmd* c, int wv,
   } else if (c->op == kCoopSym) {
     lds_d* Sl = (lds_d*)lds + c->g[0].C;
     const int ld = c->g[0].ldc, nn = c->g[0].M;
+    if (c->g[0].Nn == 64 && nw == 4) {
+      // padded 64 x 64, four waves: every lane reads its 16 elements and their mirror images, all waves meet, then the averages
+      // are written (a + b = b + a: an element and its mirror get the same bits as from the loop below; the pad is zero and
+      // stays zero).  The loop below pays an LDS round trip in each of its 16 rows per wave.
+      double own[16], mir[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = l + 64 * (wv + 4 * u), i = e >> 6, j = e & 63;
+        own[u] = Sl[i * ld + j];
+        mir[u] = Sl[j * ld + i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = l + 64 * (wv + 4 * u), i = e >> 6, j = e & 63;
+        Sl[i * ld + j] = 0.5 * (own[u] + mir[u]);
+      }
+      return;
+    }
     for (int i = wv; i < nn; i += nw)
       for (int j = l; j < i; j += 64) {
         const double v = 0.5 * (Sl[i * ld + j] + Sl[j * ld + i]);
@@ -2473,7 +2492,27 @@ struct Solver {
         }
         wsync();
         if (coop) {
-          coop_run(kCoopSym, 1, gdesc(false, S, lds, S, lds, S, lds, n, n, n, 1.0, 0, 4), g_none, g_none);  // S <- (S + S')/2
+          coop_run(kCoopSym, 1, gdesc(false, S, lds, S, lds, S, lds, n, np, n, 1.0, 0, 4), g_none, g_none);  // S <- (S + S')/2 (Nn carries the padded size)
+        } else if constexpr (NPC == 32 || NPC == 48) {
+          // S <- (S + S')/2 without a branch: every lane reads its NPC^2 / 64 elements of the padded matrix and their mirror
+          // images, then writes the averages (a + b = b + a: the element and its mirror get the same bits, as the loop below
+          // gives them; the pad is zero and stays zero).  The loop below is a divergent branch with an LDS round trip in
+          // each of its 16-36 iterations.
+          constexpr int EPL = NPC * NPC / 64;
+          lds_d* const Sl = (lds_d*)S;
+          double own[EPL], mir[EPL];
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            const int e = T + 64 * u, i = e / NPC, j = e % NPC;
+            own[u] = Sl[i * lds + j];
+            mir[u] = Sl[j * lds + i];
+          }
+          wsync();
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            const int e = T + 64 * u, i = e / NPC, j = e % NPC;
+            Sl[i * lds + j] = 0.5 * (own[u] + mir[u]);
+          }
         } else {
           Walk w = start(by_n);
           for (int e = T; e < n * n; e += 64, step(by_n, w)) {  // S <- (S + S')/2

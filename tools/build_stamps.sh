@@ -5,4 +5,4 @@ set -e
 cd "$(dirname "$0")/../altro-mpc-icra2021_amd/csrc"
 python3 gen_dpp_blocks.py dpp_blocks.inc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 \
-  -DALTRO_PHASE_STAMPS "$@" -o libaltro_hip_stamps.so altro_batch.hip
+  -DALTRO_PHASE_STAMPS -DALTRO_WIDE_SINGLE_TU "$@" -o libaltro_hip_stamps.so altro_batch.hip
