@@ -161,6 +161,14 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 __device__ __forceinline__ bool wave_any(bool f) { return __ballot(f) != 0ull; }
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1
+template <int B, int E, typename F>
+__device__ __forceinline__ void wfor(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    wfor<B + 1, E>(f);
+  }
+}
 
 // C[M x Nn] (ldc) = (ACC ? C : 0) + scale * sum_k AT[k][i] B[k][j];  M, Nn multiples of 16, K of 4.
 // A strip of NT output tiles shares the A fragment; the fragments of k-step s+1 are requested before
@@ -336,6 +344,9 @@ __device__ __forceinline__ long long wstamp() {
 // arrays in HBM carry everything else.  ALTRO_WIDE_SPLIT=0 compiles the old single body (same arithmetic, same results).
 #ifndef ALTRO_WIDE_SPLIT
 #define ALTRO_WIDE_SPLIT 1
+#endif
+#ifndef ALTRO_WIDE_FACTOR_DPP
+#define ALTRO_WIDE_FACTOR_DPP 1   // factor_solve_dpp (L spread over the lanes); 0: factor_solve_lane (L whole in every lane)
 #endif
 
 
@@ -2156,8 +2167,77 @@ struct Solver {
     e = __builtin_fma(-x, y, 1.0);
     return __builtin_fma(y, e, y);
   }
+  // The same factorisation and the same solves -- element for element the same operands in the same order -- with L spread
+  // over the lanes instead of whole in every lane: lane r of each 16-lane row holds row r of the triangle (MP doubles instead
+  // of MP (MP + 1) / 2: 24 VGPRs against 156 at MP = 12), an element of another row arrives as the DPP operand of the FMA
+  // that needs it (row_newbcast).  Right-looking step j: the pivot and f_c = L_cj come from lanes j and c, every lane updates
+  // its own row: MP (MP - 1) / 2 FMAs per lane where the replicated form had MP (MP^2 - 1) / 6.  All four rows of the wave hold
+  // the same copy, so a lane solves for its column (c0 + T) whatever row it sits in.
+  template <int MP>
+  __device__ __forceinline__ bool factor_solve_dpp(double* facout) {
+    const int ldh = ly.ldh, ldu = ly.ldu;
+    const lds_d* Hl = (const lds_d*)Huu;
+    const int r = T & 15;
+    double a[MP], inv[MP];
+#pragma unroll
+    for (int c = 0; c < MP; ++c) a[c] = Hl[(r < MP ? r : MP - 1) * ldu + c];  // row r (its part above the diagonal is never used)
+    bool fail = false;
+    wfor<0, MP>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const double dj = row_bcast<J>(a[J]);
+      fail = fail | !(dj > 0.0);
+      inv[J] = rcp_nr(dj);
+      const double f = a[J] * inv[J];  // L[r][J] (meaningful for r > J)
+      wfor<J + 1, MP>([&](auto cc) {
+        constexpr int Cc = decltype(cc)::value;
+        a[Cc] = __builtin_fma(-a[J], row_bcast<Cc>(f), a[Cc]);   // a[r][c] -= a[r][J] f_c, f_c = L[c][J] from lane c
+      });
+      a[J] = (r > J) ? f : a[J];
+    });
+    if (fail) return true;  // wave-uniform: every lane saw the same pivots
+    if (facout != nullptr) {  // the factor of this knot, for the costate sweep: lane r writes row r (1 / D_r on the diagonal)
+      double diag = 0.0;
+      wfor<0, MP>([&](auto jc) { diag = (r == decltype(jc)::value) ? inv[decltype(jc)::value] : diag; });
+#pragma unroll
+      for (int c = 0; c < MP; ++c)
+        if (T < MP && c <= T) facout[T * (T + 1) / 2 + c] = (c == T) ? diag : a[c];
+    }
+    for (int c0 = 0; c0 <= np; c0 += 64) {
+      const int c = c0 + T;
+      const bool mine = (c < n) || (c == np);
+      const lds_d* hc = (const lds_d*)Hux + (mine ? c : 0);
+      double q[MP];
+#pragma unroll
+      for (int i = 0; i < MP; ++i) q[i] = hc[i * ldh];
+      wfor<0, MP>([&](auto kc) {            // forward: L y = b  (L[i][k] = element k of lane i)
+        constexpr int K = decltype(kc)::value;
+        wfor<K + 1, MP>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          q[I] = __builtin_fma(-row_bcast<I>(a[K]), q[K], q[I]);
+        });
+      });
+#pragma unroll
+      for (int i = 0; i < MP; ++i) q[i] *= inv[i];
+      wfor<0, MP>([&](auto kr) {            // backward: L' x = y  (L[k][i] = element i of lane k), k = MP - 1 .. 0
+        constexpr int K = MP - 1 - decltype(kr)::value;
+        wfor<0, K>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          q[I] = __builtin_fma(-row_bcast<K>(a[I]), q[K], q[I]);
+        });
+      });
+      if (mine) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i) Kl[i * ldh + c] = 0.0 - q[i];  // rows >= m: zero
+      }
+    }
+    return false;
+  }
+
   template <int MP>
   __device__ __forceinline__ bool factor_solve_lane(double* facout) {
+#if ALTRO_WIDE_FACTOR_DPP
+    return factor_solve_dpp<MP>(facout);
+#endif
     const int ldh = ly.ldh, ldu = ly.ldu;
     const lds_d* Hl = (const lds_d*)Huu;
     double a[MP][MP], inv[MP];
