@@ -346,7 +346,10 @@ __device__ __forceinline__ long long wstamp() {
 #define ALTRO_WIDE_SPLIT 1
 #endif
 #ifndef ALTRO_WIDE_FACTOR_DPP
-#define ALTRO_WIDE_FACTOR_DPP 1   // factor_solve_dpp (L spread over the lanes); 0: factor_solve_lane (L whole in every lane)
+// control-size classes from this one on factor with L spread over the lanes (factor_solve_dpp), the smaller ones with L whole
+// in every lane (factor_solve_lane).  Bit-identical; measured per 30 fused steps: MC = 16 at (30, 15): 389 -> 367 ms, MC = 12
+// (quadruped): 422 -> 418, MC = 4 at n = 16: 69.4 -> 71.1 (the broadcasts cost more than the 20 FMAs they save).
+#define ALTRO_WIDE_FACTOR_DPP 12
 #endif
 
 
@@ -2170,7 +2173,8 @@ struct Solver {
   // The same factorisation and the same solves -- element for element the same operands in the same order -- with L spread
   // over the lanes instead of whole in every lane: lane r of each 16-lane row holds row r of the triangle (MP doubles instead
   // of MP (MP + 1) / 2: 24 VGPRs against 156 at MP = 12), an element of another row arrives as the DPP operand of the FMA
-  // that needs it (row_newbcast).  Right-looking step j: the pivot and f_c = L_cj come from lanes j and c, every lane updates
+  // that needs it (row_newbcast; written with plain operators so that hipcc contracts the products into the same FMAs as in
+  // factor_solve_lane -- with explicit __builtin_fma the results differed in the last bits).  Right-looking step j: the pivot and f_c = L_cj come from lanes j and c, every lane updates
   // its own row: MP (MP - 1) / 2 FMAs per lane where the replicated form had MP (MP^2 - 1) / 6.  All four rows of the wave hold
   // the same copy, so a lane solves for its column (c0 + T) whatever row it sits in.
   template <int MP>
@@ -2190,7 +2194,7 @@ struct Solver {
       const double f = a[J] * inv[J];  // L[r][J] (meaningful for r > J)
       wfor<J + 1, MP>([&](auto cc) {
         constexpr int Cc = decltype(cc)::value;
-        a[Cc] = __builtin_fma(-a[J], row_bcast<Cc>(f), a[Cc]);   // a[r][c] -= a[r][J] f_c, f_c = L[c][J] from lane c
+        a[Cc] -= a[J] * row_bcast<Cc>(f);   // a[r][c] -= a[r][J] f_c, f_c = L[c][J] from lane c
       });
       a[J] = (r > J) ? f : a[J];
     });
@@ -2213,7 +2217,7 @@ struct Solver {
         constexpr int K = decltype(kc)::value;
         wfor<K + 1, MP>([&](auto ic) {
           constexpr int I = decltype(ic)::value;
-          q[I] = __builtin_fma(-row_bcast<I>(a[K]), q[K], q[I]);
+          q[I] -= row_bcast<I>(a[K]) * q[K];
         });
       });
 #pragma unroll
@@ -2222,7 +2226,7 @@ struct Solver {
         constexpr int K = MP - 1 - decltype(kr)::value;
         wfor<0, K>([&](auto ic) {
           constexpr int I = decltype(ic)::value;
-          q[I] = __builtin_fma(-row_bcast<K>(a[I]), q[K], q[I]);
+          q[I] -= row_bcast<K>(a[I]) * q[K];
         });
       });
       if (mine) {
@@ -2235,9 +2239,7 @@ struct Solver {
 
   template <int MP>
   __device__ __forceinline__ bool factor_solve_lane(double* facout) {
-#if ALTRO_WIDE_FACTOR_DPP
-    return factor_solve_dpp<MP>(facout);
-#endif
+    if constexpr (MP >= ALTRO_WIDE_FACTOR_DPP) return factor_solve_dpp<MP>(facout);
     const int ldh = ly.ldh, ldu = ly.ldu;
     const lds_d* Hl = (const lds_d*)Huu;
     double a[MP][MP], inv[MP];
