@@ -3106,7 +3106,10 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
 #ifndef ALTRO_WIDE_WAVES_SM
 #define ALTRO_WIDE_WAVES_SM 2
 #endif
-constexpr int wide_waves(int MC, bool SM) { return SM ? (MC <= 8 ? ALTRO_WIDE_WAVES_SM : 1) : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
+#ifndef ALTRO_WIDE_WAVES_SM12
+#define ALTRO_WIDE_WAVES_SM12 1   // m = 9 .. 16 (the quadruped): measured at 2 again in round 4 with L spread over the lanes: see DESIGN 3b
+#endif
+constexpr int wide_waves(int MC, bool SM) { return SM ? (MC <= 8 ? ALTRO_WIDE_WAVES_SM : ALTRO_WIDE_WAVES_SM12) : (MC == 4 || MC == 8) ? ALTRO_WIDE_WAVES_SMALL : 1; }
 
 // threads per block: the n, m <= 16 instantiations are always one wave; the others may be launched as a cooperative
 // block of four (wide_block_threads)
