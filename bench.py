@@ -344,9 +344,9 @@ def secondary_configs(which, K, W, emit=None, state_dims=(8, 16, 32, 48, 64), gr
             # launch configuration of the point in the committed profile: one wave per four instances (n = 8), per instance
             # (n <= 48) or a cooperative block of four waves per instance (wide_block_threads)
             wg = 256 if n > 48 else 64
-            # (n = 32 and n = 48 share kernel, grid and block: the profile tells them apart by their order, `point`)
-            tk = ("state_dim", "solve_kernel<8, 4" if n == 8 else "wide_kernel<4, true>" if n <= 16 else "wide_kernel<4, false>",
-                  {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg, "point": 1 if n == 48 else 0})
+            # (every sweep point has an instantiation of its own since the padded n became a template argument)
+            tk = ("state_dim", "solve_kernel<8, 4" if n == 8 else "wide_kernel<4, true" if n <= 16 else "wide_kernel<4, false, %d" % ((n + 15) // 16 * 16),
+                  {"grid_size": (B // 4 * 64) if n == 8 else B * wg, "workgroup_size": wg, "point": 0})
             done(_secondary_line("random_linear_mpc n=%d m=4 N=50" % n, "state_dim sweep point n=%d m=4 N=50 batch=%d on 1 GPU (BASELINE configs[3])" % (n, B),
                                  kern, "valu_fp64" if n == 8 else "mfma", n, 4, 50, B, K3, W, mp, altro, traffic_key=tk, grp=grp))
             mp.solver.close()
