@@ -345,6 +345,7 @@ __device__ __forceinline__ long long wstamp() {
 #ifndef ALTRO_WIDE_SPLIT
 #define ALTRO_WIDE_SPLIT 1
 #endif
+
 #ifndef ALTRO_WIDE_FACTOR_DPP
 // control-size classes from this one on factor with L spread over the lanes (factor_solve_dpp), the smaller ones with L whole
 // in every lane (factor_solve_lane).  Bit-identical; measured per 30 fused steps: MC = 16 at (30, 15): 389 -> 367 ms, MC = 12
@@ -367,16 +368,17 @@ struct PhOut {
   long long t[5];
 #endif
 };
-template <int MC, bool SM, int OP, int NPC, bool PL>
+template <int MC, bool SM, int OP, int NPC, int PRC>
 __device__ PhOut wide_phase(unsigned long long kp, PhIn in);
 struct Resume {};
 
 // NPC: the padded state dimension as a compile-time constant (32, 48, 64; 0 = read from Params).  What SM does for n <= 16 --
 // leading dimensions, tile counts and trip counts of the product loops known to the compiler -- for the sizes of BASELINE
 // configs[3]: measured at n = 32, m = 4, batch 8192, 30 fused steps: 207 -> 158 ms, bit-identical (round 4).
-// PL ("plain"): no generic constraint rows (Pn = 0: box constraints only) as a compile-time fact -- the row tables, their
-// products and the cone code fall away: n = 16: 75.8 -> 69.9 ms per 30 steps, n = 32: 158 -> 153 (bit-identical).
-template <int MC, bool SM, int NPC = 0, bool PL = false>
+// PRC: the number of generic constraint rows as a compile-time fact (-1 = read from Params).  0 ("plain": box constraints only)
+// -- the row tables, their products and the cone code fall away: n = 16: 75.8 -> 69.9 ms per 30 steps, n = 32: 158 -> 153;
+// 16 (the quadruped's four friction pyramids) -- the row products and loops get their trip counts: 417 -> 393 ms (bit-identical).
+template <int MC, bool SM, int NPC = 0, int PRC = -1>
 struct Solver {
   static_assert(!(SM && NPC != 0), "SM fixes the padded size at 16");
   const Params& P;
@@ -441,13 +443,13 @@ struct Solver {
 
   __device__ __forceinline__ Solver(const Params& p, double* lds)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : NPC ? NPC : p.np), mp(SM ? 16 : NPC ? 16 : p.mp), nz(p.n + p.m),
-        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(PL ? 0 : p.Pn), Pp(PL ? 0 : p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, PL ? 0 : p.Pn, SM ? 0 : p.compact)) {
+        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(PRC >= 0 ? PRC : p.Pn), Pp(PRC >= 0 ? ((PRC + 3) & ~3) : p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, PRC >= 0 ? PRC : p.Pn, SM ? 0 : p.compact)) {
     init(lds, true);
   }
   // a phase function's view of the same instance: same pointers, LDS as the kernel left it
   __device__ __forceinline__ Solver(const Params& p, double* lds, Resume)
       : P(p), T(threadIdx.x), inst(blockIdx.x), n(p.n), m(p.m), N(p.N), np(SM ? 16 : NPC ? NPC : p.np), mp(SM ? 16 : NPC ? 16 : p.mp), nz(p.n + p.m),
-        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(PL ? 0 : p.Pn), Pp(PL ? 0 : p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, PL ? 0 : p.Pn, SM ? 0 : p.compact)) {
+        nzp(SM ? 32 : NPC ? NPC + 16 : p.np + p.mp), Pn(PRC >= 0 ? PRC : p.Pn), Pp(PRC >= 0 ? ((PRC + 3) & ~3) : p.Pp), ly(lds_layout(SM ? 16 : NPC ? NPC : p.n, SM ? 16 : NPC ? 16 : p.m, PRC >= 0 ? PRC : p.Pn, SM ? 0 : p.compact)) {
     init(lds, false);
   }
   __device__ __forceinline__ void init(double* lds, bool fresh) {
@@ -514,7 +516,7 @@ struct Solver {
   }
   __device__ __forceinline__ RollOut do_rollout(bool open, double alpha) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN, NPC, PL>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL, NPC, PL>(kp, ph_in(alpha));
+      const PhOut o = open ? wide_phase<MC, SM, PH_ROLL_OPEN, NPC, PRC>(kp, ph_in()) : wide_phase<MC, SM, PH_ROLL, NPC, PRC>(kp, ph_in(alpha));
       RollOut r;
       r.J = o.a; r.cmax = o.b;
       r.limit = (o.flags & 1) != 0; r.unchanged = (o.flags & 2) != 0; r.tiny = (o.flags & 4) != 0;
@@ -525,7 +527,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_backward(double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = wide_phase<MC, SM, PH_BACKWARD, NPC, PL>(kp, ph_in());
+      const PhOut o = wide_phase<MC, SM, PH_BACKWARD, NPC, PRC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b; dtiny = (o.flags & 2) != 0;
       ph_stamps(o);
       return (o.flags & 1) != 0;
@@ -535,7 +537,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_adjoint_lds(bool full, double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = full ? wide_phase<MC, SM, PH_ADJ_FULL, NPC, PL>(kp, ph_in()) : wide_phase<MC, SM, PH_ADJ_CONF, NPC, PL>(kp, ph_in());
+      const PhOut o = full ? wide_phase<MC, SM, PH_ADJ_FULL, NPC, PRC>(kp, ph_in()) : wide_phase<MC, SM, PH_ADJ_CONF, NPC, PRC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b;
       return (o.flags & 1) != 0;
     } else {
@@ -565,7 +567,7 @@ struct Solver {
   }
   __device__ __forceinline__ bool do_grad_adjoint_row_full(double& dV1, double& dV2) {
     if constexpr (ALTRO_WIDE_SPLIT != 0) {
-      const PhOut o = wide_phase<MC, SM, PH_GRAD_ADJ_ROW_FULL, NPC, PL>(kp, ph_in());
+      const PhOut o = wide_phase<MC, SM, PH_GRAD_ADJ_ROW_FULL, NPC, PRC>(kp, ph_in());
       dV1 = o.a; dV2 = o.b;
       return (o.flags & 1) != 0;
     } else {
@@ -573,19 +575,19 @@ struct Solver {
     }
   }
   __device__ __forceinline__ bool do_grad_adjoint_row() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) return (wide_phase<MC, SM, PH_GRAD_ADJ_ROW, NPC, PL>(kp, ph_in()).flags & 1) != 0;
+    if constexpr (ALTRO_WIDE_SPLIT != 0) return (wide_phase<MC, SM, PH_GRAD_ADJ_ROW, NPC, PRC>(kp, ph_in()).flags & 1) != 0;
     else return grad_adjoint_row();
   }
   __device__ __forceinline__ void do_dual_update() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_DUAL, NPC, PL>(kp, ph_in());
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_DUAL, NPC, PRC>(kp, ph_in());
     else dual_update();
   }
   __device__ __forceinline__ void do_shift() {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_SHIFT, NPC, PL>(kp, ph_in());
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_SHIFT, NPC, PRC>(kp, ph_in());
     else shift(true, true);
   }
   __device__ __forceinline__ void do_plant_step(int step) {
-    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_PLANT, NPC, PL>(kp, ph_in(0.0, step));
+    if constexpr (ALTRO_WIDE_SPLIT != 0) (void)wide_phase<MC, SM, PH_PLANT, NPC, PRC>(kp, ph_in(0.0, step));
     else plant_step(step);
   }
 
@@ -3045,13 +3047,13 @@ __device__ __forceinline__ double uniform_f64(double v) {
 
 // One phase of the solver as a function of its own (see PhIn above).  The arguments arrive in VGPRs: what is wave-uniform is
 // made scalar again first thing, so that addresses and loop bounds derived from it stay in the scalar unit.
-template <int MC, bool SM, int OP, int NPC, bool PL>
+template <int MC, bool SM, int OP, int NPC, int PRC>
 __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhIn in) {
   extern __shared__ double lds[];
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kp), hi = __builtin_amdgcn_readfirstlane((unsigned)(kp >> 32));
   typedef const __attribute__((address_space(4))) Params* KP;   // the kernel-argument segment: constant memory, scalar loads
   const Params& P = *(const Params*)(KP)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-  Solver<MC, SM, NPC, PL> s(P, lds, Resume{});
+  Solver<MC, SM, NPC, PRC> s(P, lds, Resume{});
   s.cur = __builtin_amdgcn_readfirstlane(in.cur);
   s.kref = __builtin_amdgcn_readfirstlane(in.kref);
   s.mu = uniform_f64(in.mu);
@@ -3066,7 +3068,7 @@ __device__ __attribute__((noinline)) PhOut wide_phase(unsigned long long kp, PhI
   o.h = 0ull;
   o.flags = 0;
   if constexpr (OP == PH_ROLL_OPEN || OP == PH_ROLL) {
-    const typename Solver<MC, SM, NPC, PL>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
+    const typename Solver<MC, SM, NPC, PRC>::RollOut r = s.rollout(OP == PH_ROLL_OPEN, OP == PH_ROLL_OPEN ? 0.0 : uniform_f64(in.a));
     o.a = r.J; o.b = r.cmax;
     o.flags = (r.limit ? 1 : 0) | (r.unchanged ? 2 : 0) | (r.tiny ? 4 : 0);
   } else if constexpr (OP == PH_BACKWARD) {
@@ -3113,14 +3115,14 @@ constexpr int wide_waves(int MC, bool SM) { return SM ? (MC <= 8 ? ALTRO_WIDE_WA
 
 // threads per block: the n, m <= 16 instantiations are always one wave; the others may be launched as a cooperative
 // block of four (wide_block_threads)
-template <int MC, bool SM, int NPC = 0, bool PL = false>
+template <int MC, bool SM, int NPC = 0, int PRC = -1>
 __global__ void __launch_bounds__(SM ? 64 : 256, wide_waves(MC, SM)) wide_kernel(Params P, int mpc, int first_step, int nsteps) {
   extern __shared__ double lds[];
   if (!SM && threadIdx.x >= 64) {  // helper waves: no solver state, only products on command
     coop_helper(lds, lds_layout(P.n, P.m, P.Pn, P.compact).cmd);
     return;
   }
-  Solver<MC, SM, NPC, PL> s(P, lds);
+  Solver<MC, SM, NPC, PRC> s(P, lds);
   s.kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();   // P is the first argument: offset 0
   s.run(mpc, first_step, nsteps);
 }
@@ -3147,15 +3149,15 @@ __global__ void __launch_bounds__(64) wide_shift_kernel(Params P, int primal, in
 typedef void (*wide_kernel_t)(Params, int, int, int);
 inline int wide_class(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : 0; }
 
-// Every instantiation of the library: X(translation unit, MC, SM, NPC, PL).  The library is built from several translation
+// Every instantiation of the library: X(translation unit, MC, SM, NPC, PRC).  The library is built from several translation
 // units compiled side by side (_lib.build): altro_batch.hip declares all of these `extern`, wide_inst.hip defines the ones of
 // the unit it is compiled for (-DALTRO_WIDE_TU=k).
 #define ALTRO_WIDE_KERNELS(X)                                                                                   \
-  X(0, 4, true, 0, false) X(0, 4, true, 0, true) X(0, 8, true, 0, false) X(0, 4, false, 0, false) X(0, 0, false, 0, false) \
-  X(1, 12, true, 0, false) X(1, 16, true, 0, false) X(1, 8, false, 0, false) X(1, 8, false, 32, false)            \
-  X(2, 12, false, 0, false) X(2, 16, false, 0, false) X(2, 12, false, 32, false) X(2, 16, false, 32, false)        \
-  X(3, 4, false, 32, false) X(3, 4, false, 48, false) X(3, 4, false, 64, false)                                   \
-  X(4, 4, false, 32, true) X(4, 4, false, 48, true) X(4, 4, false, 64, true)
+  X(0, 4, true, 0, -1) X(0, 4, true, 0, 0) X(0, 8, true, 0, -1) X(0, 4, false, 0, -1) X(0, 0, false, 0, -1)         \
+  X(1, 12, true, 0, -1) X(1, 16, true, 0, -1) X(1, 8, false, 0, -1) X(1, 8, false, 32, -1) X(1, 12, true, 0, 16)    \
+  X(2, 12, false, 0, -1) X(2, 16, false, 0, -1) X(2, 12, false, 32, -1) X(2, 16, false, 32, -1)                    \
+  X(3, 4, false, 32, -1) X(3, 4, false, 48, -1) X(3, 4, false, 64, -1)                                            \
+  X(4, 4, false, 32, 0) X(4, 4, false, 48, 0) X(4, 4, false, 64, 0)
 constexpr int kWideTUs = 5;
 #if !defined(ALTRO_DEV_HEADLINE_ONLY)
 #if defined(ALTRO_WIDE_TU)
@@ -3194,28 +3196,28 @@ ALTRO_WIDE_KERNELS(ALTRO_WIDE_DECLARE)
 #endif
 #endif
 
-// plain: the problem has no generic constraint rows (box constraints only)
+// nrows: the number of generic constraint rows of the problem (0: box constraints only)
 #ifndef ALTRO_WIDE_TU   // (naming a kernel instantiates it: the dispatch exists in the main translation unit only)
-inline wide_kernel_t wide_kernel_for(int n, int m, bool plain) {
+inline wide_kernel_t wide_kernel_for(int n, int m, int nrows) {
 #ifdef ALTRO_DEV_HEADLINE_ONLY  // development builds (tools/build_stamps.sh -DALTRO_DEV_HEADLINE_ONLY): one small instantiation
 #ifndef ALTRO_DEV_WIDE_KERNEL
 #define ALTRO_DEV_WIDE_KERNEL wide_kernel<4, true>
 #endif
-  (void)plain;
+  (void)nrows;
   return ALTRO_DEV_WIDE_KERNEL;  // e.g. '-DALTRO_DEV_WIDE_KERNEL=wide_kernel<4,false>' (30 s instead of 4 min)
 #else
-  const bool sm = n <= 16 && m <= 16;
+  const bool sm = n <= 16 && m <= 16, plain = nrows == 0;
   const int np = (n + 15) & ~15;
   switch (wide_class(m)) {
     case 4:   // the m <= 4 sweeps of the reference (state dimension 2 .. 64): padded n compile-time, and "no rows" where it is so
-      if (sm) return plain ? wide_kernel<4, true, 0, true> : wide_kernel<4, true>;
-      if (np == 32) return plain ? wide_kernel<4, false, 32, true> : wide_kernel<4, false, 32>;
-      if (np == 48) return plain ? wide_kernel<4, false, 48, true> : wide_kernel<4, false, 48>;
-      if (np == 64) return plain ? wide_kernel<4, false, 64, true> : wide_kernel<4, false, 64>;
+      if (sm) return plain ? wide_kernel<4, true, 0, 0> : wide_kernel<4, true>;
+      if (np == 32) return plain ? wide_kernel<4, false, 32, 0> : wide_kernel<4, false, 32>;
+      if (np == 48) return plain ? wide_kernel<4, false, 48, 0> : wide_kernel<4, false, 48>;
+      if (np == 64) return plain ? wide_kernel<4, false, 64, 0> : wide_kernel<4, false, 64>;
       return wide_kernel<4, false>;
-    // (m = 5 .. 16: the reference's control-dimension sweep runs at n = 30 -- padded 32)
+    // (m = 5 .. 16: the reference's control-dimension sweep runs at n = 30 -- padded 32; the quadruped has sixteen rows)
     case 8: return sm ? wide_kernel<8, true> : np == 32 ? wide_kernel<8, false, 32> : wide_kernel<8, false>;
-    case 12: return sm ? wide_kernel<12, true> : np == 32 ? wide_kernel<12, false, 32> : wide_kernel<12, false>;
+    case 12: return sm ? (nrows == 16 ? wide_kernel<12, true, 0, 16> : wide_kernel<12, true>) : np == 32 ? wide_kernel<12, false, 32> : wide_kernel<12, false>;
     case 16: return sm ? wide_kernel<16, true> : np == 32 ? wide_kernel<16, false, 32> : wide_kernel<16, false>;
     default: return wide_kernel<0, false>;
   }

@@ -536,7 +536,7 @@ struct WideBackend {
     con_locked = true;
     const size_t bytes = lds_bytes();
     if (bytes > 160 * 1024) WFAIL(ALTRO_ERR_UNSUPPORTED, "problem does not fit the 160 KB of LDS of one CU");
-    WCHK(hipFuncSetAttribute((const void*)wide_kernel_for(d.n, d.m, Pn == 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    WCHK(hipFuncSetAttribute((const void*)wide_kernel_for(d.n, d.m, Pn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     WCHK(hipFuncSetAttribute((const void*)wide_shift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return ALTRO_OK;
   }
@@ -569,7 +569,7 @@ struct WideBackend {
       // from the polished trajectory and the projected multipliers, as after solve!(::ALTROSolver)
       const int kref0 = kref;
       for (int s = 0; s < nsteps && !rc; ++s) {
-        hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn == 0), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step + s, 1);
+        hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step + s, 1);
         rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
         if (rc) err = "launch of the solve kernel failed";
         kref = first_step + s + 1;
@@ -577,7 +577,7 @@ struct WideBackend {
       }
       if (rc) kref = kref0;
     } else {
-      hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn == 0), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
+      hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), mpc, first_step, nsteps);
       rc = hipGetLastError() == hipSuccess ? ALTRO_OK : ALTRO_ERR_HIP;
       if (rc) err = "launch of the solve kernel failed";
       if (!rc && o.projected_newton) rc = polish_launch();
@@ -601,7 +601,7 @@ struct WideBackend {
     WCHK(hipSetDevice(device));
     int rc = prepare_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn == 0), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), 2, step, 1);
+    hipLaunchKernelGGL(wide_kernel_for(d.n, d.m, Pn), dim3(d.batch), dim3(wide_block_threads(d.n, d.m, lds_bytes(), coop_mode)), lds_bytes(), stream, params(), 2, step, 1);
     WCHK(hipGetLastError());
     kref = step + 1;
     return ALTRO_OK;
